@@ -1,0 +1,284 @@
+/* fmj.h — C-ABI of the MI355X-native batched locomotion step ("fmj" = farms-mujoco).
+ *
+ * This is the drop-in boundary for ONE hot path of farmsim/farms_mujoco: the per-step
+ * physics + hydrodynamic drag + sensor readout.  Every entry point below names the
+ * reference interface (file:line under the reference tree) it replaces.
+ *
+ *   - plain C, `extern "C"`, plain pointers and sizes, no torch / HIP types in signatures
+ *     (a HIP stream is passed as `void*`; NULL = the null stream);
+ *   - the library borrows caller-owned DEVICE buffers for the duration of a call and owns
+ *     only its immutable device copy of the model (fp32) and small index tables;
+ *   - every function returns an int status (0 = FMJ_OK), never throws, and records a
+ *     message retrievable with fmj_last_error();
+ *   - all per-environment arrays are fp32, batch-first, C-contiguous: `[n_envs, n, ...]`,
+ *     one wavefront owns one environment row, so a row is one coalesced access.
+ *
+ * Quaternions: `xquat`/`qpos[3:7]` are w,x,y,z (MuJoCo convention); AnimatData link rows are
+ * x,y,z,w (farms_core convention, permutation at reference physics.py:458,466).
+ */
+#ifndef FMJ_H_
+#define FMJ_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FMJ_ABI_VERSION 1
+
+/* ---- status codes ------------------------------------------------------------------------ */
+enum {
+  FMJ_OK = 0,
+  FMJ_ERR_ARG = 1,          /* NULL pointer / bad size / inconsistent model             */
+  FMJ_ERR_UNSUPPORTED = 2,  /* model feature outside the supported subset               */
+  FMJ_ERR_HIP = 3,          /* HIP runtime error (message has hipGetErrorString)        */
+  FMJ_ERR_NODEVICE = 4      /* no GPU visible                                           */
+};
+
+/* ---- joint / geom enums (values follow MuJoCo's mjtJoint / mjtGeom) ---------------------- */
+enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, FMJ_JNT_HINGE = 3 };
+enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_BOX = 6 };
+
+/* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
+ * reference simulation.py:157-161,176-179) */
+enum { FMJ_WARN_BADQPOS = 1, FMJ_WARN_BADQVEL = 2, FMJ_WARN_BADQACC = 4, FMJ_WARN_CONTACTFULL = 8 };
+
+/* ---- AnimatData column convention ("sc" in farms_core; reference physics.py:427-523) ------
+ * farms_core is not vendored in the reference, so the integers are defined HERE and nowhere
+ * else; host code queries them through fmj_sc(). Link CoM position at columns 0..2 and xfrc
+ * force/torque at 0..2 / 3..5 are fixed by reference drag.pyx:189-191,265-267. */
+enum {
+  FMJ_LINK_COM_POS = 0,    /* 3 */
+  FMJ_LINK_COM_QUAT = 3,   /* 4, xyzw */
+  FMJ_LINK_URDF_POS = 7,   /* 3 */
+  FMJ_LINK_URDF_QUAT = 10, /* 4, xyzw */
+  FMJ_LINK_COM_LINVEL = 14,/* 3 */
+  FMJ_LINK_COM_ANGVEL = 17,/* 3 */
+  FMJ_LINK_SIZE = 20,
+  FMJ_JOINT_POSITION = 0,
+  FMJ_JOINT_VELOCITY = 1,
+  FMJ_JOINT_FORCE = 2,     /* 3 (force sensors, unused unless use_frc_trq_sensors) */
+  FMJ_JOINT_TORQUE3 = 5,   /* 3 */
+  FMJ_JOINT_TORQUE = 8,    /* motor torque = sum of the 3 actuatorfrc (physics.py:510-524) */
+  FMJ_JOINT_LIMIT_FORCE = 9,
+  FMJ_JOINT_SIZE = 12,
+  FMJ_CONTACT_REACTION = 0, FMJ_CONTACT_FRICTION = 3, FMJ_CONTACT_TOTAL = 6,
+  FMJ_CONTACT_POSITION = 9, FMJ_CONTACT_SIZE = 12,
+  FMJ_XFRC_FORCE = 0, FMJ_XFRC_TORQUE = 3, FMJ_XFRC_SIZE = 6
+};
+
+/* ---- model: HOST pointers, fp64, MuJoCo mjModel naming ------------------------------------
+ * Replaces the `const mjModel*` argument of mujoco.mj_step (reached through
+ * reference simulation.py:53,83-89,156).  Supported subset = what reference mjcf.py emits
+ * for an animat: one kinematic forest, each body carries 0 or 1 joint
+ * (free / hinge / slide), explicit inertials, joint spring-dampers, position / velocity /
+ * motor actuators on joints, Euler integrator with implicit joint damping. */
+typedef struct fmj_model {
+  int32_t abi_version;      /* = FMJ_ABI_VERSION */
+  int32_t nbody, njnt, nq, nv, nu, ngeom;
+  int32_t nM;               /* number of non-zeros of the sparse joint-space inertia    */
+  double timestep;          /* option.timestep (reference mjcf.py:1187-1192,1329)      */
+  double gravity[3];        /* option.gravity  (mjcf.py:1336-1341)                     */
+
+  /* bodies [nbody]; body 0 = world */
+  const int32_t* body_parentid;
+  const int32_t* body_rootid;
+  const int32_t* body_jntadr;   /* -1 if the body has no joint */
+  const int32_t* body_dofadr;   /* -1 if no dof */
+  const int32_t* body_dofnum;
+  const double* body_pos;       /* [nbody,3] */
+  const double* body_quat;      /* [nbody,4] wxyz */
+  const double* body_ipos;      /* [nbody,3] */
+  const double* body_iquat;     /* [nbody,4] */
+  const double* body_mass;      /* [nbody]   */
+  const double* body_inertia;   /* [nbody,3] principal moments */
+
+  /* joints [njnt] */
+  const int32_t* jnt_type;
+  const int32_t* jnt_qposadr;
+  const int32_t* jnt_dofadr;
+  const int32_t* jnt_bodyid;
+  const double* jnt_pos;        /* [njnt,3] */
+  const double* jnt_axis;       /* [njnt,3] */
+  const double* jnt_stiffness;  /* [njnt]   */
+  const int32_t* jnt_limited;   /* [njnt]   */
+  const double* jnt_range;      /* [njnt,2] */
+  const double* jnt_solref;     /* [njnt,2] limit solref */
+  const double* jnt_solimp;     /* [njnt,5] limit solimp */
+  const double* jnt_margin;     /* [njnt]   */
+  const double* qpos0;          /* [nq] */
+
+  /* dofs [nv] */
+  const int32_t* dof_bodyid;
+  const int32_t* dof_jntid;
+  const int32_t* dof_parentid;  /* -1 at a tree root */
+  const int32_t* dof_Madr;      /* start of row i in the sparse M (row = i, parent(i), ...) */
+  const double* dof_armature;
+  const double* dof_damping;
+  const double* dof_invweight0; /* [nv] (M^-1)_ii at qpos0; limit/contact regulariser     */
+
+  /* actuators [nu]: force = gain*ctrl + bias0 + bias1*q + bias2*qdot (joint transmission) */
+  const int32_t* actuator_jntid;
+  const double* actuator_gain;       /* gainprm[0] */
+  const double* actuator_bias;       /* [nu,3] biasprm[0:3] */
+  const int32_t* actuator_ctrllimited;
+  const double* actuator_ctrlrange;  /* [nu,2] */
+  const int32_t* actuator_forcelimited;
+  const double* actuator_forcerange; /* [nu,2] (task.py:279-286 rewrites this at run time) */
+
+  /* collision geoms [ngeom] (config 4: animat geoms vs plane) */
+  const int32_t* geom_type;
+  const int32_t* geom_bodyid;
+  const double* geom_size;      /* [ngeom,3] */
+  const double* geom_pos;       /* [ngeom,3] body frame */
+  const double* geom_quat;      /* [ngeom,4] */
+  const double* geom_friction;  /* [ngeom,3] */
+  const double* geom_solref;    /* [ngeom,2] */
+  const double* geom_solimp;    /* [ngeom,5] */
+  const double* body_invweight0;/* [nbody,2] translational, rotational */
+
+  /* constraint solver options (mjcf.py:1330-1403) */
+  int32_t solver_iterations;
+  int32_t max_contacts;         /* per environment */
+  double impratio;
+  double solver_tolerance;
+} fmj_model;
+
+/* ---- per-env device buffers for the physics step -------------------------------------------
+ * The mjData fields the reference reads or writes around mj_step
+ * (reference task.py:317,332,343-346; physics.py:449-524).  DEVICE pointers, fp32. */
+typedef struct fmj_data {
+  float* qpos;               /* [n_envs,nq]      in/out */
+  float* qvel;               /* [n_envs,nv]      in/out */
+  const float* ctrl;         /* [n_envs,nu]      in     */
+  const float* qpos_spring;  /* [n_envs,nq]      in  (per-env: task.py:343-346)          */
+  const float* xfrc_applied; /* [n_envs,nbody,6] in, world frame force(3),torque(3); may be NULL */
+  /* derived fields, valid for the state BEFORE integration (mj_step semantics) */
+  float* xpos;               /* [n_envs,nbody,3] */
+  float* xquat;              /* [n_envs,nbody,4] wxyz */
+  float* xipos;              /* [n_envs,nbody,3] */
+  float* sensordata;         /* [n_envs,nsensordata] layout: fmj_sensor_layout()          */
+  float* qacc;               /* [n_envs,nv] may be NULL */
+  float* time;               /* [n_envs]   may be NULL */
+  int32_t* status;           /* [n_envs]   warning bits, OR-accumulated                   */
+} fmj_data;
+
+/* sensordata layout, in the order reference mjcf.py:950-1002 adds the sensors */
+typedef struct fmj_sensor_layout_t {
+  int32_t nsensordata;
+  int32_t framelinvel_adr;   /* + 6*(body-1)     : framelinvel(3), frameangvel(3) interleaved per link */
+  int32_t jointpos_adr;      /* + 3*j            : jointpos, jointvel, jointlimitfrc per non-free joint */
+  int32_t actuatorfrc_adr;   /* + a              : actuatorfrc per actuator */
+  int32_t first_link_body;   /* bodies [first_link_body, nbody) carry link sensors */
+  int32_t first_sensor_jnt;  /* joints [first_sensor_jnt, njnt) carry joint sensors */
+} fmj_sensor_layout_t;
+
+/* ---- AnimatData ring-buffer rows (reference task.py:62,158,208-216) --------------------------
+ * `[buffer_size, n_envs, n, width]` fp32 device tensors; `*_row` point at ONE ring index. */
+typedef struct fmj_rows {
+  float* links;     /* [n_envs,n_links,FMJ_LINK_SIZE]   */
+  float* joints;    /* [n_envs,n_joints,FMJ_JOINT_SIZE] */
+  float* xfrc;      /* [n_envs,n_links,FMJ_XFRC_SIZE]   */
+  float* contacts;  /* [n_envs,n_contact_sensors,FMJ_CONTACT_SIZE] or NULL */
+} fmj_rows;
+
+/* unit scaling (farms_core SimulationUnitScaling; reference physics.py:428-524) */
+typedef struct fmj_units {
+  float meters, newtons, torques, velocity, angular_velocity, kilograms;
+} fmj_units;
+
+/* water + per-link swimming constants (reference drag.pyx:271-306,333-387) */
+typedef struct fmj_water {
+  float surface;       /* WaterProperties._surface (1e8 when sph, drag.pyx:386-387) */
+  float density;       /* stored, unused by the reference arithmetic (drag.pyx:142) */
+  float viscosity;
+  float velocity[3];   /* global frame */
+  float gravity;       /* -9.81 hard-coded at drag.pyx:409 */
+  int32_t use_buoyancy;
+} fmj_water;
+
+typedef struct fmj_ctx fmj_ctx;   /* opaque */
+
+/* ---- lifecycle ---------------------------------------------------------------------------- */
+/* Replaces mjcf.Physics.from_mjcf_model (reference simulation.py:53): validates the model,
+ * builds the level / ancestor tables, uploads the fp32 device copy. `device` = HIP ordinal. */
+int fmj_create(const fmj_model* model, int32_t n_envs, int32_t device, fmj_ctx** out);
+void fmj_destroy(fmj_ctx* ctx);
+const char* fmj_last_error(void);
+int fmj_abi_version(void);
+int fmj_get_sensor_layout(const fmj_ctx* ctx, fmj_sensor_layout_t* out);
+/* LDS bytes / VGPR-independent facts the host needs for reporting */
+int fmj_kernel_info(const fmj_ctx* ctx, int32_t* lds_bytes_per_env, int32_t* threads_per_env);
+
+/* ---- swimming links (SwimmingHandler.__init__, reference drag.pyx:333-387) ------------------
+ * links_index / xfrc_index: row of each swimming link in links / xfrc arrays;
+ * body_index: MuJoCo body id of each swimming link (datalinks2xfrc, physics.py:385-393);
+ * coefficients [ns,2,3]; masses, heights, densities [ns]. HOST pointers, copied. */
+int fmj_set_swimming(fmj_ctx* ctx, int32_t ns, const int32_t* links_index,
+                     const int32_t* xfrc_index, const int32_t* body_index,
+                     const double* coefficients, const double* masses,
+                     const double* heights, const double* densities);
+
+/* link / joint readout maps (get_physics2data_maps, reference physics.py:188-393):
+ * link row i <- body links_body[i]; joint row j <- joint joints_jnt[j]. HOST pointers. */
+int fmj_set_readout_maps(fmj_ctx* ctx, int32_t n_links, const int32_t* links_body,
+                         int32_t n_joints, const int32_t* joints_jnt);
+
+/* ---- the hot path ------------------------------------------------------------------------- */
+/* mujoco.mj_step(model, data) x n_steps for every env (reference simulation.py:156,175 via
+ * dm_control Environment.step -> Physics.step; legacy_step=False, simulation.py:36-37,45).
+ * ctrl_step_stride: element stride between successive steps' ctrl rows (0 = same ctrl). */
+int fmj_step(fmj_ctx* ctx, const fmj_data* d, int32_t n_steps, int64_t ctrl_step_stride,
+             void* hip_stream);
+
+/* SwimmingHandler.step(iteration) (reference drag.pyx:389-411 -> drag_forces :152-268) for
+ * every env: reads rows->links, writes rows->xfrc (rows of links above the surface are left
+ * untouched, drag.pyx:192-194).  If xfrc_applied != NULL also performs the glue the reference
+ * leaves to an external callback: xfrc_applied[body] = R_body * (F,T) * units,
+ * zero for links above the surface. */
+int fmj_drag(fmj_ctx* ctx, const fmj_rows* rows, const fmj_water* water,
+             const fmj_units* units, float* xfrc_applied, void* hip_stream);
+
+/* physics2data(physics, iteration, data, maps, units, links_only) (reference
+ * physics.py:527-545): mjData fields -> AnimatData rows with unit scaling. */
+int fmj_physics2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows,
+                     const fmj_units* units, int32_t links_only, void* hip_stream);
+
+/* Fused loop: for s in [0,n_steps): physics2data(row (it0+s)%buffer) -> drag -> xfrc_applied
+ * -> ctrl -> mj_step, state and derived fields resident in LDS between steps
+ * (ExperimentTask.before_step + Environment.step, reference task.py:168-186, simulation.py:155-156).
+ * rows_base point at ring index 0; row_stride_* = elements between ring indices.
+ * controller: 0 = ctrl tape (ctrl + s*ctrl_step_stride), 1 = built-in travelling-wave
+ * position controller (see fmj_wave_controller). */
+typedef struct fmj_wave_controller {
+  const float* amplitude;   /* [nu] DEVICE, per actuator (0 for non-position actuators) */
+  const float* phase_lag;   /* [nu] DEVICE */
+  const float* env_phase;   /* [n_envs] DEVICE */
+  float frequency;          /* Hz */
+} fmj_wave_controller;
+
+typedef struct fmj_fused_args {
+  int32_t n_steps;
+  int32_t iteration0;       /* task.iteration of the first step */
+  int32_t buffer_size;      /* ring length (task.py:62) */
+  int32_t do_readout;       /* write links/joints rows each step */
+  int32_t do_drag;          /* SwimmingHandler.step + xfrc glue each step */
+  int32_t controller;       /* 0 tape, 1 wave */
+  int64_t ctrl_step_stride;
+  int64_t row_stride_links, row_stride_joints, row_stride_xfrc;
+  fmj_rows rows_base;
+  fmj_water water;
+  fmj_units units;
+  fmj_wave_controller wave;
+} fmj_fused_args;
+
+int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);
+
+/* enum query so host code never hard-codes column integers: name is e.g. "LINK_COM_POS" */
+int fmj_sc(const char* name);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FMJ_H_ */

@@ -1,0 +1,1130 @@
+/* fmj_oracle.c — CPU fp64 restatement of the farms_mujoco hot path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * shared object; the product path (farms_mujoco_amd/) never does.
+ *
+ * PARITY UNPINNED versus MuJoCo: the arithmetic of the step lives in the third-party `mujoco`
+ * C library, which the reference neither vendors nor pins (reference requirements.txt:1-9;
+ * only call sites: simulation.py:53,83-89,156,175, sensors.pyx:70) and which is not installed
+ * here; the reference holds no tests or golden vectors.  What follows restates MuJoCo's
+ * published forward-dynamics pipeline (mj_step = mj_forward + Euler with implicit joint
+ * damping) for the feature subset reference mjcf.py switches on, and is
+ * pinned instead by analytic known-answer tests and an independent body-frame RNEA
+ * (tests/test_oracle_*.py).
+ *
+ * The parts the reference OWNS are restated line by line:
+ *   drag            <- reference farms_mujoco/swimming/drag.pyx:12-268
+ *   physics2data    <- reference farms_mujoco/simulation/physics.py:449-524
+ *   contacts2data   <- reference farms_mujoco/sensors/sensors.pyx:20-190
+ *
+ * Conventions: spatial vectors are [rot(3); lin(3)]; all c* quantities are expressed in world
+ * axes about subtree_com[body_rootid]; quaternions w,x,y,z except AnimatData rows (x,y,z,w).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <pthread.h>
+
+#include "../include/fmj.h"
+
+#define MINVAL 1e-15
+#define MAXVAL 1e10
+#define MINIMP 0.0001
+#define MAXIMP 0.9999
+
+/* ------------------------------------------------------------------------------------------ */
+/* small vector / quaternion helpers (MuJoCo engine_util_blas / engine_util_spatial semantics)  */
+
+static void cross3(double* r, const double* a, const double* b) {
+  double x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static double dotn(const double* a, const double* b, int n) {
+  double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s;
+}
+static void mul_quat(double* r, const double* a, const double* b) {
+  double t[4] = {a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3],
+                 a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2],
+                 a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1],
+                 a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]};
+  memcpy(r, t, sizeof t);
+}
+static void normalize4(double* q) {
+  double n = sqrt(dotn(q, q, 4));
+  if (n < MINVAL) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  for (int i = 0; i < 4; i++) q[i] /= n;
+}
+static void quat2mat(double* m, const double* q) {
+  double q00 = q[0] * q[0], q11 = q[1] * q[1], q22 = q[2] * q[2], q33 = q[3] * q[3];
+  m[0] = q00 + q11 - q22 - q33; m[4] = q00 - q11 + q22 - q33; m[8] = q00 - q11 - q22 + q33;
+  m[1] = 2 * (q[1] * q[2] - q[0] * q[3]); m[2] = 2 * (q[1] * q[3] + q[0] * q[2]);
+  m[3] = 2 * (q[1] * q[2] + q[0] * q[3]); m[5] = 2 * (q[2] * q[3] - q[0] * q[1]);
+  m[6] = 2 * (q[1] * q[3] - q[0] * q[2]); m[7] = 2 * (q[2] * q[3] + q[0] * q[1]);
+}
+static void rot_vec_quat(double* r, const double* v, const double* q) {
+  double m[9]; quat2mat(m, q);
+  double x = m[0] * v[0] + m[1] * v[1] + m[2] * v[2];
+  double y = m[3] * v[0] + m[4] * v[1] + m[5] * v[2];
+  double z = m[6] * v[0] + m[7] * v[1] + m[8] * v[2];
+  r[0] = x; r[1] = y; r[2] = z;
+}
+static void axis_angle2quat(double* q, const double* axis, double angle) {
+  if (angle == 0) { q[0] = 1; q[1] = q[2] = q[3] = 0; return; }
+  double s = sin(angle * 0.5);
+  q[0] = cos(angle * 0.5); q[1] = axis[0] * s; q[2] = axis[1] * s; q[3] = axis[2] * s;
+}
+/* cinert[10] * v[6] */
+static void mul_inert_vec(double* r, const double* i, const double* v) {
+  r[0] = i[0] * v[0] + i[3] * v[1] + i[4] * v[2] - i[8] * v[4] + i[7] * v[5];
+  r[1] = i[3] * v[0] + i[1] * v[1] + i[5] * v[2] + i[8] * v[3] - i[6] * v[5];
+  r[2] = i[4] * v[0] + i[5] * v[1] + i[2] * v[2] - i[7] * v[3] + i[6] * v[4];
+  r[3] = i[8] * v[1] - i[7] * v[2] + i[9] * v[3];
+  r[4] = i[6] * v[2] - i[8] * v[0] + i[9] * v[4];
+  r[5] = i[7] * v[0] - i[6] * v[1] + i[9] * v[5];
+}
+/* motion cross: vel x v */
+static void cross_motion(double* r, const double* vel, const double* v) {
+  double t[6];
+  cross3(t, vel, v);
+  double a[3], b[3];
+  cross3(a, vel, v + 3); cross3(b, vel + 3, v);
+  t[3] = a[0] + b[0]; t[4] = a[1] + b[1]; t[5] = a[2] + b[2];
+  memcpy(r, t, sizeof t);
+}
+/* force cross: vel x* f */
+static void cross_force(double* r, const double* vel, const double* f) {
+  double t[6], a[3], b[3];
+  cross3(a, vel, f); cross3(b, vel + 3, f + 3);
+  t[0] = a[0] + b[0]; t[1] = a[1] + b[1]; t[2] = a[2] + b[2];
+  cross3(t + 3, vel, f + 3);
+  memcpy(r, t, sizeof t);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* per-env workspace                                                                           */
+
+typedef struct ws_t {
+  double *xpos, *xquat, *xmat, *xipos, *ximat, *xanchor, *xaxis, *subtree_com, *subtree_mass;
+  double *cinert, *crb, *cdof, *cdof_dot, *cvel, *cacc, *cfrc;
+  double *qM, *qLD, *qLDiagInv, *qH, *qHDiagInv;
+  double *qfrc_bias, *qfrc_passive, *qfrc_actuator, *qfrc_xfrc, *qfrc_smooth, *qacc_smooth;
+  double *qfrc_constraint, *qacc, *qacc_warmstart, *actuator_force, *tmpv;
+  /* constraints */
+  int nefc, ncon, maxefc;
+  double *efc_J, *efc_pos, *efc_margin, *efc_R, *efc_aref, *efc_b, *efc_AR, *efc_force, *efc_diagApprox;
+  double *efc_MiJT;
+  int *efc_type, *efc_id;
+  /* contacts */
+  int *con_geom, *con_plane; double *con_pos, *con_frame, *con_dist, *con_mu; int *con_efc;
+  double *jointlimitfrc;
+  double meaninertia;
+} ws_t;
+
+enum { EFC_LIMIT = 0, EFC_CONTACT = 1 };
+
+static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
+
+static ws_t* ws_new(const fmj_model* m) {
+  ws_t* w = (ws_t*)calloc(1, sizeof(ws_t));
+  int nb = m->nbody, nv = m->nv, nj = m->njnt, nM = m->nM;
+  w->xpos = dalloc(3 * nb); w->xquat = dalloc(4 * nb); w->xmat = dalloc(9 * nb);
+  w->xipos = dalloc(3 * nb); w->ximat = dalloc(9 * nb);
+  w->xanchor = dalloc(3 * nj); w->xaxis = dalloc(3 * nj);
+  w->subtree_com = dalloc(3 * nb); w->subtree_mass = dalloc(nb);
+  w->cinert = dalloc(10 * nb); w->crb = dalloc(10 * nb);
+  w->cdof = dalloc(6 * nv); w->cdof_dot = dalloc(6 * nv);
+  w->cvel = dalloc(6 * nb); w->cacc = dalloc(6 * nb); w->cfrc = dalloc(6 * nb);
+  w->qM = dalloc(nM); w->qLD = dalloc(nM); w->qLDiagInv = dalloc(nv);
+  w->qH = dalloc(nM); w->qHDiagInv = dalloc(nv);
+  w->qfrc_bias = dalloc(nv); w->qfrc_passive = dalloc(nv); w->qfrc_actuator = dalloc(nv);
+  w->qfrc_xfrc = dalloc(nv); w->qfrc_smooth = dalloc(nv); w->qacc_smooth = dalloc(nv);
+  w->qfrc_constraint = dalloc(nv); w->qacc = dalloc(nv); w->qacc_warmstart = dalloc(nv);
+  w->actuator_force = dalloc(m->nu); w->tmpv = dalloc(nv);
+  int maxcon = m->max_contacts > 0 ? m->max_contacts : 0;
+  w->maxefc = 2 * nj + 4 * maxcon;
+  int me = w->maxefc;
+  w->efc_J = dalloc((size_t)me * nv); w->efc_pos = dalloc(me); w->efc_margin = dalloc(me);
+  w->efc_R = dalloc(me); w->efc_aref = dalloc(me); w->efc_b = dalloc(me);
+  w->efc_AR = dalloc((size_t)me * me); w->efc_force = dalloc(me); w->efc_diagApprox = dalloc(me);
+  w->efc_MiJT = dalloc((size_t)me * nv);
+  w->efc_type = (int*)calloc(me ? me : 1, sizeof(int)); w->efc_id = (int*)calloc(me ? me : 1, sizeof(int));
+  w->con_geom = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
+  w->con_efc = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
+  w->con_plane = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
+  w->con_pos = dalloc(3 * maxcon); w->con_frame = dalloc(9 * maxcon);
+  w->con_dist = dalloc(maxcon); w->con_mu = dalloc(maxcon);
+  w->jointlimitfrc = dalloc(nj);
+  return w;
+}
+static void ws_free(ws_t* w) {
+  double** p[] = {&w->xpos, &w->xquat, &w->xmat, &w->xipos, &w->ximat, &w->xanchor, &w->xaxis,
+                  &w->subtree_com, &w->subtree_mass, &w->cinert, &w->crb, &w->cdof, &w->cdof_dot,
+                  &w->cvel, &w->cacc, &w->cfrc, &w->qM, &w->qLD, &w->qLDiagInv, &w->qH, &w->qHDiagInv,
+                  &w->qfrc_bias, &w->qfrc_passive, &w->qfrc_actuator, &w->qfrc_xfrc, &w->qfrc_smooth,
+                  &w->qacc_smooth, &w->qfrc_constraint, &w->qacc, &w->qacc_warmstart,
+                  &w->actuator_force, &w->tmpv, &w->efc_J, &w->efc_pos, &w->efc_margin, &w->efc_R,
+                  &w->efc_aref, &w->efc_b, &w->efc_AR, &w->efc_force, &w->efc_diagApprox,
+                  &w->efc_MiJT, &w->con_pos, &w->con_frame, &w->con_dist, &w->con_mu, &w->jointlimitfrc};
+  for (size_t i = 0; i < sizeof p / sizeof p[0]; i++) free(*p[i]);
+  free(w->efc_type); free(w->efc_id); free(w->con_geom); free(w->con_efc); free(w->con_plane);
+  free(w);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* position stage: mj_kinematics, mj_comPos, mj_crb, mj_factorM        */
+
+static void kinematics(const fmj_model* m, ws_t* w, const double* qpos) {
+  /* world */
+  w->xpos[0] = w->xpos[1] = w->xpos[2] = 0;
+  w->xquat[0] = 1; w->xquat[1] = w->xquat[2] = w->xquat[3] = 0;
+  quat2mat(w->xmat, w->xquat);
+  memcpy(w->xipos, w->xpos, 3 * sizeof(double)); memcpy(w->ximat, w->xmat, 9 * sizeof(double));
+  for (int i = 1; i < m->nbody; i++) {
+    double* xpos = w->xpos + 3 * i; double* xquat = w->xquat + 4 * i;
+    int j = m->body_jntadr[i];
+    int pid = m->body_parentid[i];
+    if (j >= 0 && m->jnt_type[j] == FMJ_JNT_FREE) {
+      int qa = m->jnt_qposadr[j];
+      memcpy(xpos, qpos + qa, 3 * sizeof(double));
+      memcpy(xquat, qpos + qa + 3, 4 * sizeof(double));
+      normalize4(xquat);
+      memcpy(w->xanchor + 3 * j, xpos, 3 * sizeof(double));
+      memcpy(w->xaxis + 3 * j, m->jnt_axis + 3 * j, 3 * sizeof(double));
+    } else {
+      /* body frame from parent */
+      double v[3];
+      rot_vec_quat(v, m->body_pos + 3 * i, w->xquat + 4 * pid);
+      for (int k = 0; k < 3; k++) xpos[k] = w->xpos[3 * pid + k] + v[k];
+      mul_quat(xquat, w->xquat + 4 * pid, m->body_quat + 4 * i);
+      if (j >= 0) {
+        double* xaxis = w->xaxis + 3 * j; double* xanchor = w->xanchor + 3 * j;
+        rot_vec_quat(xaxis, m->jnt_axis + 3 * j, xquat);
+        rot_vec_quat(xanchor, m->jnt_pos + 3 * j, xquat);
+        for (int k = 0; k < 3; k++) xanchor[k] += xpos[k];
+        int qa = m->jnt_qposadr[j];
+        double dq = qpos[qa] - m->qpos0[qa];
+        if (m->jnt_type[j] == FMJ_JNT_SLIDE) {
+          for (int k = 0; k < 3; k++) xpos[k] += xaxis[k] * dq;
+        } else { /* hinge */
+          double qloc[4];
+          axis_angle2quat(qloc, m->jnt_axis + 3 * j, dq);
+          mul_quat(xquat, xquat, qloc);
+          rot_vec_quat(v, m->jnt_pos + 3 * j, xquat);
+          for (int k = 0; k < 3; k++) xpos[k] = xanchor[k] - v[k];
+        }
+      }
+    }
+    normalize4(xquat);
+    quat2mat(w->xmat + 9 * i, xquat);
+    /* inertial frame */
+    double v[3], iq[4];
+    rot_vec_quat(v, m->body_ipos + 3 * i, xquat);
+    for (int k = 0; k < 3; k++) w->xipos[3 * i + k] = xpos[k] + v[k];
+    mul_quat(iq, xquat, m->body_iquat + 4 * i);
+    quat2mat(w->ximat + 9 * i, iq);
+  }
+}
+
+static void com_pos(const fmj_model* m, ws_t* w) {
+  int nb = m->nbody;
+  for (int i = 0; i < nb; i++) {
+    w->subtree_mass[i] = m->body_mass[i];
+    for (int k = 0; k < 3; k++) w->subtree_com[3 * i + k] = m->body_mass[i] * w->xipos[3 * i + k];
+  }
+  for (int i = nb - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    w->subtree_mass[p] += w->subtree_mass[i];
+    for (int k = 0; k < 3; k++) w->subtree_com[3 * p + k] += w->subtree_com[3 * i + k];
+  }
+  for (int i = 0; i < nb; i++) {
+    if (w->subtree_mass[i] < MINVAL) memcpy(w->subtree_com + 3 * i, w->xipos + 3 * i, 3 * sizeof(double));
+    else for (int k = 0; k < 3; k++) w->subtree_com[3 * i + k] /= w->subtree_mass[i];
+  }
+  memset(w->cinert, 0, 10 * sizeof(double));
+  for (int i = 1; i < nb; i++) {
+    const double* mat = w->ximat + 9 * i; const double* in = m->body_inertia + 3 * i;
+    double mass = m->body_mass[i], dif[3];
+    for (int k = 0; k < 3; k++) dif[k] = w->xipos[3 * i + k] - w->subtree_com[3 * m->body_rootid[i] + k];
+    double* r = w->cinert + 10 * i;
+    /* mat * diag(in) * mat' */
+    r[0] = mat[0] * mat[0] * in[0] + mat[1] * mat[1] * in[1] + mat[2] * mat[2] * in[2];
+    r[1] = mat[3] * mat[3] * in[0] + mat[4] * mat[4] * in[1] + mat[5] * mat[5] * in[2];
+    r[2] = mat[6] * mat[6] * in[0] + mat[7] * mat[7] * in[1] + mat[8] * mat[8] * in[2];
+    r[3] = mat[0] * mat[3] * in[0] + mat[1] * mat[4] * in[1] + mat[2] * mat[5] * in[2];
+    r[4] = mat[0] * mat[6] * in[0] + mat[1] * mat[7] * in[1] + mat[2] * mat[8] * in[2];
+    r[5] = mat[3] * mat[6] * in[0] + mat[4] * mat[7] * in[1] + mat[5] * mat[8] * in[2];
+    r[0] += mass * (dif[1] * dif[1] + dif[2] * dif[2]);
+    r[1] += mass * (dif[0] * dif[0] + dif[2] * dif[2]);
+    r[2] += mass * (dif[0] * dif[0] + dif[1] * dif[1]);
+    r[3] -= mass * dif[0] * dif[1]; r[4] -= mass * dif[0] * dif[2]; r[5] -= mass * dif[1] * dif[2];
+    r[6] = mass * dif[0]; r[7] = mass * dif[1]; r[8] = mass * dif[2]; r[9] = mass;
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    int bi = m->jnt_bodyid[j], da = m->jnt_dofadr[j];
+    double off[3];
+    for (int k = 0; k < 3; k++) off[k] = w->subtree_com[3 * m->body_rootid[bi] + k] - w->xanchor[3 * j + k];
+    const double* axis = w->xaxis + 3 * j;
+    double* cd = w->cdof + 6 * da;
+    if (m->jnt_type[j] == FMJ_JNT_FREE) {
+      memset(cd, 0, 18 * sizeof(double));
+      for (int k = 0; k < 3; k++) cd[6 * k + 3 + k] = 1;
+      for (int k = 0; k < 3; k++) {
+        double* c = cd + 6 * (3 + k);
+        const double* mat = w->xmat + 9 * bi;
+        c[0] = mat[k]; c[1] = mat[k + 3]; c[2] = mat[k + 6];
+        cross3(c + 3, c, off);
+      }
+    } else if (m->jnt_type[j] == FMJ_JNT_SLIDE) {
+      cd[0] = cd[1] = cd[2] = 0; memcpy(cd + 3, axis, 3 * sizeof(double));
+    } else {
+      memcpy(cd, axis, 3 * sizeof(double)); cross3(cd + 3, axis, off);
+    }
+  }
+}
+
+static void crb(const fmj_model* m, ws_t* w) {
+  memcpy(w->crb, w->cinert, 10 * m->nbody * sizeof(double));
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int k = 0; k < 10; k++) w->crb[10 * p + k] += w->crb[10 * i + k];
+  }
+  memset(w->qM, 0, m->nM * sizeof(double));
+  for (int i = 0; i < m->nv; i++) {
+    int adr = m->dof_Madr[i];
+    double buf[6];
+    mul_inert_vec(buf, w->crb + 10 * m->dof_bodyid[i], w->cdof + 6 * i);
+    w->qM[adr] = m->dof_armature[i];
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) w->qM[adr++] += dotn(w->cdof + 6 * j, buf, 6);
+  }
+}
+
+/* sparse L'DL in MuJoCo's dof_Madr/dof_parentid storage (mj_factorI) */
+static void factor(const fmj_model* m, const double* M, double* LD, double* DiagInv) {
+  int nv = m->nv, nM = m->nM;
+  memcpy(LD, M, nM * sizeof(double));
+  for (int k = nv - 1; k >= 0; k--) {
+    int kk = m->dof_Madr[k], ki = kk + 1;
+    for (int i = m->dof_parentid[k]; i >= 0; i = m->dof_parentid[i], ki++) {
+      double t = LD[ki] / LD[kk];
+      int cnt = (i < nv - 1 ? m->dof_Madr[i + 1] : nM) - m->dof_Madr[i];
+      for (int c = 0; c < cnt; c++) LD[m->dof_Madr[i] + c] -= t * LD[ki + c];
+      LD[ki] = t;
+    }
+    DiagInv[k] = 1.0 / LD[kk];
+  }
+}
+static void solve_ld(const fmj_model* m, double* x, const double* LD, const double* DiagInv) {
+  int nv = m->nv;
+  for (int i = nv - 1; i >= 0; i--) {
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[j] -= LD[a++] * x[i];
+  }
+  for (int i = 0; i < nv; i++) x[i] *= DiagInv[i];
+  for (int i = 0; i < nv; i++) {
+    int a = m->dof_Madr[i] + 1;
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j]) x[i] -= LD[a++] * x[j];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* velocity stage: mj_comVel, mj_passive, mj_rne  (Appendix A.4, A.5)                            */
+
+static void com_vel(const fmj_model* m, ws_t* w, const double* qvel) {
+  memset(w->cvel, 0, 6 * sizeof(double));
+  for (int i = 1; i < m->nbody; i++) {
+    double cvel[6];
+    memcpy(cvel, w->cvel + 6 * m->body_parentid[i], sizeof cvel);
+    int bda = m->body_dofadr[i], j = m->body_jntadr[i];
+    if (j >= 0) {
+      if (m->jnt_type[j] == FMJ_JNT_FREE) {
+        memset(w->cdof_dot + 6 * bda, 0, 18 * sizeof(double));
+        for (int k = 0; k < 3; k++) for (int c = 0; c < 6; c++) cvel[c] += w->cdof[6 * (bda + k) + c] * qvel[bda + k];
+        for (int k = 3; k < 6; k++) cross_motion(w->cdof_dot + 6 * (bda + k), cvel, w->cdof + 6 * (bda + k));
+        for (int k = 3; k < 6; k++) for (int c = 0; c < 6; c++) cvel[c] += w->cdof[6 * (bda + k) + c] * qvel[bda + k];
+      } else {
+        cross_motion(w->cdof_dot + 6 * bda, cvel, w->cdof + 6 * bda);
+        for (int c = 0; c < 6; c++) cvel[c] += w->cdof[6 * bda + c] * qvel[bda];
+      }
+    }
+    memcpy(w->cvel + 6 * i, cvel, sizeof cvel);
+  }
+}
+
+static void passive(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, const double* qpos_spring) {
+  for (int i = 0; i < m->nv; i++) w->qfrc_passive[i] = -m->dof_damping[i] * qvel[i];
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->jnt_type[j] == FMJ_JNT_FREE || m->jnt_stiffness[j] == 0) continue;
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    w->qfrc_passive[da] += -m->jnt_stiffness[j] * (qpos[qa] - qpos_spring[qa]);
+  }
+}
+
+static void rne(const fmj_model* m, ws_t* w, const double* qvel) {
+  memset(w->cacc, 0, 6 * sizeof(double));
+  for (int k = 0; k < 3; k++) w->cacc[3 + k] = -m->gravity[k];
+  memset(w->cfrc, 0, 6 * sizeof(double));
+  for (int i = 1; i < m->nbody; i++) {
+    double* cacc = w->cacc + 6 * i;
+    memcpy(cacc, w->cacc + 6 * m->body_parentid[i], 6 * sizeof(double));
+    int bda = m->body_dofadr[i];
+    for (int d = 0; d < m->body_dofnum[i]; d++)
+      for (int c = 0; c < 6; c++) cacc[c] += w->cdof_dot[6 * (bda + d) + c] * qvel[bda + d];
+    double t[6], t1[6];
+    mul_inert_vec(w->cfrc + 6 * i, w->cinert + 10 * i, cacc);
+    mul_inert_vec(t, w->cinert + 10 * i, w->cvel + 6 * i);
+    cross_force(t1, w->cvel + 6 * i, t);
+    for (int c = 0; c < 6; c++) w->cfrc[6 * i + c] += t1[c];
+  }
+  for (int i = m->nbody - 1; i > 0; i--) {
+    int p = m->body_parentid[i];
+    if (p > 0) for (int c = 0; c < 6; c++) w->cfrc[6 * p + c] += w->cfrc[6 * i + c];
+  }
+  for (int i = 0; i < m->nv; i++) w->qfrc_bias[i] = dotn(w->cdof + 6 * i, w->cfrc + 6 * m->dof_bodyid[i], 6);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* actuation (A.6) and external force accumulation (A.7)                                        */
+
+static void actuation(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, const double* ctrl) {
+  memset(w->qfrc_actuator, 0, m->nv * sizeof(double));
+  for (int a = 0; a < m->nu; a++) {
+    int j = m->actuator_jntid[a];
+    double c = ctrl ? ctrl[a] : 0.0;
+    if (m->actuator_ctrllimited[a]) c = fmin(fmax(c, m->actuator_ctrlrange[2 * a]), m->actuator_ctrlrange[2 * a + 1]);
+    double len = qpos[m->jnt_qposadr[j]], vel = qvel[m->jnt_dofadr[j]];
+    const double* b = m->actuator_bias + 3 * a;
+    double f = m->actuator_gain[a] * c + b[0] + b[1] * len + b[2] * vel;
+    if (m->actuator_forcelimited[a]) f = fmin(fmax(f, m->actuator_forcerange[2 * a]), m->actuator_forcerange[2 * a + 1]);
+    w->actuator_force[a] = f;
+    w->qfrc_actuator[m->jnt_dofadr[j]] += f;
+  }
+}
+
+/* J' * [force; torque] applied at `point` on `body` (mj_applyFT via mj_jac) */
+static void apply_ft(const fmj_model* m, const ws_t* w, const double* force, const double* torque,
+                     const double* point, int body, double* qfrc) {
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = point[k] - w->subtree_com[3 * m->body_rootid[body] + k];
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body <= 0) return;
+  for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i]) {
+    const double* cd = w->cdof + 6 * i;
+    double jp[3];
+    cross3(jp, cd, off);
+    for (int k = 0; k < 3; k++) jp[k] += cd[3 + k];
+    qfrc[i] += dotn(jp, force, 3) + dotn(cd, torque, 3);
+  }
+}
+/* dense Jacobian rows (translational jacp[3,nv], rotational jacr[3,nv]) of a world point on body */
+static void jac_point(const fmj_model* m, const ws_t* w, double* jacp, double* jacr, const double* point, int body) {
+  int nv = m->nv;
+  if (jacp) memset(jacp, 0, 3 * nv * sizeof(double));
+  if (jacr) memset(jacr, 0, 3 * nv * sizeof(double));
+  double off[3];
+  for (int k = 0; k < 3; k++) off[k] = point[k] - w->subtree_com[3 * m->body_rootid[body] + k];
+  while (body > 0 && m->body_dofnum[body] == 0) body = m->body_parentid[body];
+  if (body <= 0) return;
+  for (int i = m->body_dofadr[body] + m->body_dofnum[body] - 1; i >= 0; i = m->dof_parentid[i]) {
+    const double* cd = w->cdof + 6 * i;
+    double jp[3];
+    cross3(jp, cd, off);
+    for (int k = 0; k < 3; k++) {
+      if (jacp) jacp[k * nv + i] = jp[k] + cd[3 + k];
+      if (jacr) jacr[k * nv + i] = cd[k];
+    }
+  }
+}
+
+static void xfrc_accumulate(const fmj_model* m, ws_t* w, const double* xfrc) {
+  memset(w->qfrc_xfrc, 0, m->nv * sizeof(double));
+  if (!xfrc) return;
+  for (int i = 1; i < m->nbody; i++) {
+    const double* f = xfrc + 6 * i;
+    int nz = 0; for (int k = 0; k < 6; k++) nz |= (f[k] != 0);
+    if (nz) apply_ft(m, w, f, f + 3, w->xipos + 3 * i, i, w->qfrc_xfrc);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* constraints: joint limits + plane contacts, pyramidal cone, PGS (Appendix A.9, A.10, E)       */
+
+static void get_impedance(const double* solimp_in, double pos, double margin, double* imp) {
+  double dmin = fmin(fmax(solimp_in[0], MINIMP), MAXIMP), dmax = fmin(fmax(solimp_in[1], MINIMP), MAXIMP);
+  double width = fmax(0.0, solimp_in[2]);
+  double mid = fmin(fmax(solimp_in[3], MINIMP), MAXIMP), power = fmax(1.0, solimp_in[4]);
+  if (dmin == dmax || width <= MINVAL) { *imp = 0.5 * (dmin + dmax); return; }
+  double x = fabs((pos - margin) / width), y;
+  if (x >= 1) y = 1;
+  else if (x <= 0) y = 0;
+  else if (power == 1) y = x;
+  else if (x <= mid) y = pow(x, power) / pow(mid, power - 1);
+  else y = 1 - pow(1 - x, power) / pow(1 - mid, power - 1);
+  *imp = dmin + y * (dmax - dmin);
+}
+
+static int add_efc(const fmj_model* m, ws_t* w, const double* jrow, double pos, double margin, int type, int id) {
+  if (w->nefc >= w->maxefc) return -1;
+  int e = w->nefc++;
+  memcpy(w->efc_J + (size_t)e * m->nv, jrow, m->nv * sizeof(double));
+  w->efc_pos[e] = pos; w->efc_margin[e] = margin; w->efc_type[e] = type; w->efc_id[e] = id;
+  return e;
+}
+
+/* plane narrow phase: geom 'g' (sphere/capsule/box) vs the plane geom 'p' */
+static void add_contact(const fmj_model* m, ws_t* w, int p, int g, const double* pos, const double* n, double dist, double mu, int* warn) {
+  if (w->ncon >= m->max_contacts) { *warn |= FMJ_WARN_CONTACTFULL; return; }
+  int c = w->ncon++;
+  w->con_geom[c] = g; w->con_plane[c] = p; w->con_dist[c] = dist; w->con_mu[c] = mu;
+  memcpy(w->con_pos + 3 * c, pos, 3 * sizeof(double));
+  /* frame: x = normal, y/z = tangents (mju_makeFrame) */
+  double* f = w->con_frame + 9 * c;
+  memcpy(f, n, 3 * sizeof(double));
+  double t[3] = {0, 0, 0};
+  if (f[1] < -0.5 || f[1] > 0.5) t[2] = 1; else t[1] = 1;
+  double d = dotn(t, f, 3);
+  for (int k = 0; k < 3; k++) t[k] -= d * f[k];
+  double nn = sqrt(dotn(t, t, 3));
+  for (int k = 0; k < 3; k++) f[3 + k] = t[k] / nn;
+  cross3(f + 6, f, f + 3);
+}
+
+static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) {
+  /* plane pose */
+  int pb = m->geom_bodyid[p];
+  double pq[4], ppos[3], v[3], pm[9];
+  mul_quat(pq, w->xquat + 4 * pb, m->geom_quat + 4 * p);
+  rot_vec_quat(v, m->geom_pos + 3 * p, w->xquat + 4 * pb);
+  for (int k = 0; k < 3; k++) ppos[k] = w->xpos[3 * pb + k] + v[k];
+  quat2mat(pm, pq);
+  double n[3] = {pm[2], pm[5], pm[8]};
+  /* geom pose */
+  int gb = m->geom_bodyid[g];
+  double gq[4], gpos[3], gm[9];
+  mul_quat(gq, w->xquat + 4 * gb, m->geom_quat + 4 * g);
+  rot_vec_quat(v, m->geom_pos + 3 * g, w->xquat + 4 * gb);
+  for (int k = 0; k < 3; k++) gpos[k] = w->xpos[3 * gb + k] + v[k];
+  quat2mat(gm, gq);
+  double mu = fmax(m->geom_friction[3 * p], m->geom_friction[3 * g]);
+  const double* size = m->geom_size + 3 * g;
+  int type = m->geom_type[g];
+  if (type == FMJ_GEOM_SPHERE || type == FMJ_GEOM_CAPSULE) {
+    int nseg = type == FMJ_GEOM_CAPSULE ? 2 : 1;
+    for (int s = 0; s < nseg; s++) {
+      double c[3];
+      double sgn = nseg == 2 ? (s == 0 ? 1.0 : -1.0) : 0.0;
+      for (int k = 0; k < 3; k++) c[k] = gpos[k] + sgn * size[1] * gm[3 * k + 2];
+      double dif[3]; for (int k = 0; k < 3; k++) dif[k] = c[k] - ppos[k];
+      double dist = dotn(dif, n, 3) - size[0];
+      if (dist < 0) {  /* margin = 0 (mjcf.py:253) */
+        double pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (size[0] + 0.5 * dist);
+        add_contact(m, w, p, g, pos, n, dist, mu, warn);
+      }
+    }
+  } else if (type == FMJ_GEOM_BOX) {
+    int cnt = 0;
+    for (int corner = 0; corner < 8 && cnt < 4; corner++) {
+      double loc[3] = {(corner & 1 ? 1 : -1) * size[0], (corner & 2 ? 1 : -1) * size[1], (corner & 4 ? 1 : -1) * size[2]};
+      double c[3];
+      for (int k = 0; k < 3; k++) c[k] = gpos[k] + gm[3 * k] * loc[0] + gm[3 * k + 1] * loc[1] + gm[3 * k + 2] * loc[2];
+      double dif[3]; for (int k = 0; k < 3; k++) dif[k] = c[k] - ppos[k];
+      double dist = dotn(dif, n, 3);
+      if (dist < 0) {
+        double pos[3];
+        for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * 0.5 * dist;
+        add_contact(m, w, p, g, pos, n, dist, mu, warn);
+        cnt++;
+      }
+    }
+  }
+}
+
+static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, int* warn) {
+  int nv = m->nv;
+  w->nefc = 0; w->ncon = 0;
+  double* jrow = w->tmpv;
+  /* joint limits (mj_instantiateLimit) */
+  for (int j = 0; j < m->njnt; j++) {
+    if (!m->jnt_limited[j] || m->jnt_type[j] == FMJ_JNT_FREE) continue;
+    double value = qpos[m->jnt_qposadr[j]], margin = m->jnt_margin[j];
+    for (int side = -1; side <= 1; side += 2) {
+      double dist = side * (m->jnt_range[2 * j + (side + 1) / 2] - value);
+      if (dist < margin) {
+        memset(jrow, 0, nv * sizeof(double));
+        jrow[m->jnt_dofadr[j]] = -side;
+        int e = add_efc(m, w, jrow, dist, margin, EFC_LIMIT, j);
+        if (e >= 0) w->efc_diagApprox[e] = m->dof_invweight0[m->jnt_dofadr[j]];
+      }
+    }
+  }
+  /* contacts: every non-plane geom against every plane geom (arena vs animat, mjcf.py:251-267) */
+  for (int p = 0; p < m->ngeom; p++) {
+    if (m->geom_type[p] != FMJ_GEOM_PLANE) continue;
+    for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] != FMJ_GEOM_PLANE) collide_plane(m, w, p, g, warn);
+  }
+  double* jacp = dalloc(3 * nv);
+  for (int c = 0; c < w->ncon; c++) {
+    int g = w->con_geom[c], b = m->geom_bodyid[g];
+    jac_point(m, w, jacp, NULL, w->con_pos + 3 * c, b);
+    /* contact-frame Jacobian of (geom body - plane body); plane is static => J = -(-J_b)?
+       MuJoCo: jacdif = J(body2) - J(body1), geom1 = plane, geom2 = animat geom. */
+    const double* f = w->con_frame + 9 * c;
+    double jn[64 * 4], *jt1, *jt2;  /* nv <= 256 guard below */
+    double* buf = nv <= 64 ? jn : dalloc(3 * nv);
+    jt1 = buf + nv; jt2 = buf + 2 * nv;
+    for (int i = 0; i < nv; i++) {
+      buf[i] = f[0] * jacp[i] + f[1] * jacp[nv + i] + f[2] * jacp[2 * nv + i];
+      jt1[i] = f[3] * jacp[i] + f[4] * jacp[nv + i] + f[5] * jacp[2 * nv + i];
+      jt2[i] = f[6] * jacp[i] + f[7] * jacp[nv + i] + f[8] * jacp[2 * nv + i];
+    }
+    double mu = w->con_mu[c];
+    double tran = m->body_invweight0[2 * b] + m->body_invweight0[2 * m->geom_bodyid[w->con_plane[c]]];
+    w->con_efc[c] = w->nefc;
+    for (int r = 0; r < 4; r++) {
+      const double* jt = r < 2 ? jt1 : jt2;
+      double sgn = (r & 1) ? -1.0 : 1.0;
+      for (int i = 0; i < nv; i++) jrow[i] = buf[i] + sgn * mu * jt[i];
+      int e = add_efc(m, w, jrow, w->con_dist[c], 0.0, EFC_CONTACT, c);
+      if (e >= 0) w->efc_diagApprox[e] = tran + mu * mu * tran;
+    }
+    if (buf != jn) free(buf);
+  }
+  free(jacp);
+  /* impedance, R, aref (mj_makeImpedance, mj_referenceConstraint) */
+  for (int e = 0; e < w->nefc; e++) {
+    const double *solref, *solimp;
+    if (w->efc_type[e] == EFC_LIMIT) { solref = m->jnt_solref + 2 * w->efc_id[e]; solimp = m->jnt_solimp + 5 * w->efc_id[e]; }
+    else { int g = w->con_geom[w->efc_id[e]]; solref = m->geom_solref + 2 * g; solimp = m->geom_solimp + 5 * g; }
+    double imp; get_impedance(solimp, w->efc_pos[e], w->efc_margin[e], &imp);
+    double dmax = fmin(fmax(solimp[1], MINIMP), MAXIMP);
+    double K, B;
+    if (solref[0] > 0) {
+      double tc = fmax(solref[0], 2 * m->timestep), dr = solref[1];
+      K = 1.0 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
+      B = 2.0 / fmax(MINVAL, dmax * tc);
+    } else { K = -solref[0] / fmax(MINVAL, dmax * dmax); B = -solref[1] / fmax(MINVAL, dmax); }
+    w->efc_R[e] = fmax(MINVAL, (1 - imp) * w->efc_diagApprox[e] / imp);
+    double vel = dotn(w->efc_J + (size_t)e * nv, qvel, nv);
+    w->efc_aref[e] = -B * vel - K * imp * (w->efc_pos[e] - w->efc_margin[e]);
+  }
+  /* pyramidal: all rows of a contact share R = 2 mu^2 R_first, mu scaled by 1/sqrt(impratio) */
+  for (int c = 0; c < w->ncon; c++) {
+    int e0 = w->con_efc[c];
+    if (e0 + 4 > w->nefc) continue;
+    double mu = w->con_mu[c] / sqrt(m->impratio > 0 ? m->impratio : 1.0);
+    double Rpy = 2 * mu * mu * w->efc_R[e0];
+    for (int r = 0; r < 4; r++) w->efc_R[e0 + r] = fmax(MINVAL, Rpy);
+  }
+}
+
+static double dual_cost(const ws_t* w, const double* f) {
+  int n = w->nefc; double c = 0;
+  for (int i = 0; i < n; i++) {
+    double s = 0; for (int j = 0; j < n; j++) s += w->efc_AR[(size_t)i * n + j] * f[j];
+    c += f[i] * (0.5 * s + w->efc_b[i]);
+  }
+  return c;
+}
+
+static void solve_constraints(const fmj_model* m, ws_t* w) {
+  int nv = m->nv, n = w->nefc;
+  memset(w->qfrc_constraint, 0, nv * sizeof(double));
+  memset(w->jointlimitfrc, 0, m->njnt * sizeof(double));
+  if (n == 0) { memcpy(w->qacc, w->qacc_smooth, nv * sizeof(double)); return; }
+  /* AR = J M^-1 J' + R ; b = J qacc_smooth - aref */
+  for (int e = 0; e < n; e++) {
+    double* x = w->efc_MiJT + (size_t)e * nv;
+    memcpy(x, w->efc_J + (size_t)e * nv, nv * sizeof(double));
+    solve_ld(m, x, w->qLD, w->qLDiagInv);
+  }
+  for (int i = 0; i < n; i++) {
+    for (int j = 0; j < n; j++) w->efc_AR[(size_t)i * n + j] = dotn(w->efc_J + (size_t)i * nv, w->efc_MiJT + (size_t)j * nv, nv);
+    w->efc_AR[(size_t)i * n + i] += w->efc_R[i];
+    w->efc_b[i] = dotn(w->efc_J + (size_t)i * nv, w->qacc_smooth, nv) - w->efc_aref[i];
+  }
+  /* warm start from previous qacc (mj_fwdConstraint) */
+  for (int i = 0; i < n; i++) {
+    double jar = dotn(w->efc_J + (size_t)i * nv, w->qacc_warmstart, nv) - w->efc_aref[i];
+    w->efc_force[i] = jar < 0 ? -jar / w->efc_R[i] : 0.0;
+  }
+  if (dual_cost(w, w->efc_force) > 0) memset(w->efc_force, 0, n * sizeof(double));
+  /* PGS (mj_solPGS) */
+  double scale = 1.0 / (w->meaninertia * (nv > 1 ? nv : 1));
+  for (int it = 0; it < m->solver_iterations; it++) {
+    double improvement = 0;
+    for (int i = 0; i < n; i++) {
+      double res = w->efc_b[i];
+      for (int j = 0; j < n; j++) res += w->efc_AR[(size_t)i * n + j] * w->efc_force[j];
+      double old = w->efc_force[i];
+      double f = old - res / w->efc_AR[(size_t)i * n + i];
+      if (f < 0) f = 0;
+      double delta = f - old;
+      double change = 0.5 * delta * delta * w->efc_AR[(size_t)i * n + i] + delta * res;
+      if (change > 1e-10) { f = old; change = 0; }
+      w->efc_force[i] = f;
+      improvement -= change;
+    }
+    if (improvement * scale < m->solver_tolerance) break;
+  }
+  for (int e = 0; e < n; e++) {
+    for (int i = 0; i < nv; i++) w->qfrc_constraint[i] += w->efc_J[(size_t)e * nv + i] * w->efc_force[e];
+    if (w->efc_type[e] == EFC_LIMIT) w->jointlimitfrc[w->efc_id[e]] += w->efc_force[e];
+  }
+  memcpy(w->qacc, w->qfrc_constraint, nv * sizeof(double));
+  solve_ld(m, w->qacc, w->qLD, w->qLDiagInv);
+  for (int i = 0; i < nv; i++) w->qacc[i] += w->qacc_smooth[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sensors (Appendix A.11) in the order of reference mjcf.py:950-1002                            */
+
+static void sensors(const fmj_model* m, const ws_t* w, const double* qpos, const double* qvel, double* sd) {
+  if (!sd) return;
+  int adr = 0;
+  for (int b = 1; b < m->nbody; b++) {   /* framelinvel, frameangvel (objtype=body => inertial frame) */
+    const double* cv = w->cvel + 6 * b;
+    double dif[3], c[3];
+    for (int k = 0; k < 3; k++) dif[k] = w->xipos[3 * b + k] - w->subtree_com[3 * m->body_rootid[b] + k];
+    cross3(c, dif, cv);
+    for (int k = 0; k < 3; k++) sd[adr + k] = cv[3 + k] - c[k];
+    for (int k = 0; k < 3; k++) sd[adr + 3 + k] = cv[k];
+    adr += 6;
+  }
+  for (int j = 0; j < m->njnt; j++) {
+    if (m->jnt_type[j] == FMJ_JNT_FREE) continue;
+    sd[adr++] = qpos[m->jnt_qposadr[j]];
+    sd[adr++] = qvel[m->jnt_dofadr[j]];
+    sd[adr++] = w->jointlimitfrc[j];
+  }
+  for (int a = 0; a < m->nu; a++) sd[adr++] = w->actuator_force[a];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* mj_forward + mj_Euler                                                                        */
+
+static int forward(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, const double* ctrl,
+                   const double* qpos_spring, const double* xfrc, double* sensordata) {
+  int nv = m->nv, warn = 0;
+  kinematics(m, w, qpos);
+  com_pos(m, w);
+  crb(m, w);
+  factor(m, w->qM, w->qLD, w->qLDiagInv);
+  com_vel(m, w, qvel);
+  passive(m, w, qpos, qvel, qpos_spring);
+  rne(m, w, qvel);
+  actuation(m, w, qpos, qvel, ctrl);
+  xfrc_accumulate(m, w, xfrc);
+  for (int i = 0; i < nv; i++)
+    w->qfrc_smooth[i] = w->qfrc_passive[i] - w->qfrc_bias[i] + w->qfrc_actuator[i] + w->qfrc_xfrc[i];
+  memcpy(w->qacc_smooth, w->qfrc_smooth, nv * sizeof(double));
+  solve_ld(m, w->qacc_smooth, w->qLD, w->qLDiagInv);
+  make_constraints(m, w, qpos, qvel, &warn);
+  solve_constraints(m, w);
+  sensors(m, w, qpos, qvel, sensordata);
+  return warn;
+}
+
+static void euler(const fmj_model* m, ws_t* w, double* qpos, double* qvel) {
+  int nv = m->nv; double h = m->timestep;
+  int damped = 0;
+  for (int i = 0; i < nv; i++) damped |= (m->dof_damping[i] > 0);
+  double* qacc = w->tmpv;
+  if (!damped) memcpy(qacc, w->qacc, nv * sizeof(double));
+  else {
+    memcpy(w->qH, w->qM, m->nM * sizeof(double));
+    for (int i = 0; i < nv; i++) w->qH[m->dof_Madr[i]] += h * m->dof_damping[i];
+    factor(m, w->qH, w->qH, w->qHDiagInv);
+    for (int i = 0; i < nv; i++) qacc[i] = w->qfrc_smooth[i] + w->qfrc_constraint[i];
+    solve_ld(m, qacc, w->qH, w->qHDiagInv);
+  }
+  for (int i = 0; i < nv; i++) qvel[i] += h * qacc[i];
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == FMJ_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
+      double ax[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]};
+      double nrm = sqrt(dotn(ax, ax, 3));
+      if (nrm < MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; nrm = 0; } else for (int k = 0; k < 3; k++) ax[k] /= nrm;
+      double qr[4];
+      axis_angle2quat(qr, ax, h * nrm);
+      normalize4(qpos + qa + 3);
+      mul_quat(qpos + qa + 3, qpos + qa + 3, qr);
+    } else qpos[qa] += h * qvel[da];
+  }
+}
+
+static int bad(const double* x, int n) {
+  for (int i = 0; i < n; i++) if (!(fabs(x[i]) <= MAXVAL)) return 1;
+  return 0;
+}
+
+static double mean_inertia(const fmj_model* m) {
+  /* stat.meaninertia: mean diagonal of M at qpos0 */
+  ws_t* w = ws_new(m);
+  kinematics(m, w, m->qpos0); com_pos(m, w); crb(m, w);
+  double s = 0;
+  for (int i = 0; i < m->nv; i++) s += w->qM[m->dof_Madr[i]];
+  ws_free(w);
+  return m->nv ? s / m->nv : 1.0;
+}
+
+/* one mj_step for one env. Derived outputs are for the PRE-integration state. */
+static int step_one(const fmj_model* m, ws_t* w, double* qpos, double* qvel, const double* ctrl,
+                    const double* qpos_spring, const double* xfrc, double* sensordata) {
+  int warn = 0;
+  if (bad(qpos, m->nq)) warn |= FMJ_WARN_BADQPOS;
+  if (bad(qvel, m->nv)) warn |= FMJ_WARN_BADQVEL;
+  warn |= forward(m, w, qpos, qvel, ctrl, qpos_spring, xfrc, sensordata);
+  if (bad(w->qacc, m->nv)) warn |= FMJ_WARN_BADQACC;
+  euler(m, w, qpos, qvel);
+  memcpy(w->qacc_warmstart, w->qacc, m->nv * sizeof(double));
+  return warn;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* drag: reference farms_mujoco/swimming/drag.pyx (x,y,z,w quaternions, farms_core transform)    */
+
+static void fq_conj(const double* q, double* o) { o[0] = -q[0]; o[1] = -q[1]; o[2] = -q[2]; o[3] = q[3]; }
+static void fq_mult(const double* a, const double* b, double* o, int full) {
+  double t[4];
+  t[0] = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  t[1] = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  t[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  t[3] = full ? a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2] : 0.0;
+  o[0] = t[0]; o[1] = t[1]; o[2] = t[2]; if (full) o[3] = t[3];
+}
+/* out = quat * (vector,0) * conj(quat)  (drag.pyx:50-63 usage) */
+static void fq_rot(const double* v, const double* q, double* out) {
+  double qc[4], v4[4] = {v[0], v[1], v[2], 0.0}, t4[4];
+  fq_conj(q, qc);
+  fq_mult(q, v4, t4, 1);
+  fq_mult(t4, qc, out, 0);
+}
+
+/* drag_forces (drag.pyx:152-268) for one link; returns 1 if a force was written */
+static int drag_link(const double* link_row, double* xfrc_row, const double* coeff /*[2,3]*/,
+                     double surface, const double* water_vel, double viscosity,
+                     double mass, double height, double density, double gravity, int use_buoyancy) {
+  const double* pos = link_row + FMJ_LINK_COM_POS;           /* drag.pyx:189-191 */
+  if (pos[2] > surface) return 0;                            /* drag.pyx:193-194 */
+  const double* urdf2global = link_row + FMJ_LINK_URDF_QUAT; /* link_swimming_info, drag.pyx:43-47 */
+  const double* com2global = link_row + FMJ_LINK_COM_QUAT;
+  double global2urdf[4], com2urdf[4], urdf2com[4], lin[3], ang[3];
+  fq_conj(urdf2global, global2urdf);
+  fq_mult(global2urdf, com2global, com2urdf, 1);
+  fq_conj(com2urdf, urdf2com);
+  fq_rot(link_row + FMJ_LINK_COM_LINVEL, global2urdf, lin);  /* drag.pyx:50-63 */
+  fq_rot(link_row + FMJ_LINK_COM_ANGVEL, global2urdf, ang);
+  double buoy[3] = {0, 0, 0};
+  if (use_buoyancy) {                                        /* compute_buoyancy, drag.pyx:139-149 */
+    if (mass > 0 && pos[2] < surface) {
+      double t[3] = {0, 0, -1000 * mass * gravity / density * fmin(fmax(surface - pos[2], 0) / height, 1)};
+      fq_rot(t, global2urdf, buoy);
+    }
+  }
+  double fluid[3];
+  fq_rot(water_vel, global2urdf, fluid);                     /* drag.pyx:235-244 */
+  for (int i = 0; i < 3; i++) lin[i] -= fluid[i];
+  double force[3], torque[3];
+  for (int i = 0; i < 3; i++) {                              /* compute_force, drag.pyx:83-88 */
+    force[i] = lin[i] * lin[i];
+    if (lin[i] < 0) force[i] *= -1;
+    force[i] *= viscosity * coeff[i];
+    force[i] += buoy[i];
+  }
+  for (int i = 0; i < 3; i++) {                              /* compute_torque, drag.pyx:104-108 */
+    torque[i] = ang[i] * ang[i];
+    if (ang[i] < 0) torque[i] *= -1;
+    torque[i] *= coeff[3 + i];
+  }
+  fq_rot(force, urdf2com, force);                            /* drag.pyx:261-262 */
+  fq_rot(torque, urdf2com, torque);
+  for (int i = 0; i < 3; i++) { xfrc_row[i] = force[i]; xfrc_row[3 + i] = torque[i]; }  /* :265-267 */
+  return 1;
+}
+
+/* SwimmingHandler.step (drag.pyx:389-411) for n_envs; rows batch-first fp64.
+ * If xfrc_applied != NULL also writes the world-frame glue. */
+int fmjo_drag(int n_envs, int n_links_rows, int n_xfrc_rows, int nbody, int ns,
+              const int32_t* links_index, const int32_t* xfrc_index, const int32_t* body_index,
+              const double* coefficients, const double* masses, const double* heights, const double* densities,
+              double surface, const double* water_vel, double viscosity, double gravity, int use_buoyancy,
+              double newtons, double torques,
+              const double* links, double* xfrc, double* xfrc_applied) {
+  for (int e = 0; e < n_envs; e++) {
+    const double* L = links + (size_t)e * n_links_rows * FMJ_LINK_SIZE;
+    double* X = xfrc + (size_t)e * n_xfrc_rows * FMJ_XFRC_SIZE;
+    for (int i = 0; i < ns; i++) {
+      const double* lrow = L + (size_t)links_index[i] * FMJ_LINK_SIZE;
+      double* xrow = X + (size_t)xfrc_index[i] * FMJ_XFRC_SIZE;
+      int applied = drag_link(lrow, xrow, coefficients + 6 * i, surface, water_vel, viscosity,
+                              masses[i], heights[i], densities[i], gravity, use_buoyancy);
+      if (xfrc_applied) {
+        double* xa = xfrc_applied + ((size_t)e * nbody + body_index[i]) * 6;
+        if (!applied) { memset(xa, 0, 6 * sizeof(double)); continue; }
+        /* CoM frame == body frame (physics.py:463-466); rotate to world with com2global */
+        double f[3], t[3];
+        fq_rot(xrow, lrow + FMJ_LINK_COM_QUAT, f);
+        fq_rot(xrow + 3, lrow + FMJ_LINK_COM_QUAT, t);
+        for (int k = 0; k < 3; k++) { xa[k] = f[k] * newtons; xa[3 + k] = t[k] * torques; }
+      }
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* physics2data (reference physics.py:527-545; readers :449-466, :435-446, :481-524)             */
+
+static void physics2data_one(const fmj_model* m, const double* qpos, const double* qvel,
+                             const double* xpos, const double* xquat, const double* xipos, const double* sd,
+                             int n_links, const int32_t* links_body, int n_joints, const int32_t* joints_jnt,
+                             const double* units /*meters,newtons,torques,velocity,angular_velocity*/,
+                             int links_only, double* links, double* joints) {
+  double meters = units[0], torques = units[2], velocity = units[3], angvel = units[4];
+  int lin_adr = 0;                         /* framelinvel/frameangvel interleaved per body from body 1 */
+  int njs = 0; for (int j = 0; j < m->njnt; j++) njs += m->jnt_type[j] != FMJ_JNT_FREE;
+  int jnt_adr = 6 * (m->nbody - 1), act_adr = jnt_adr + 3 * njs;
+  for (int i = 0; i < n_links; i++) {
+    int b = links_body[i]; double* r = links + (size_t)i * FMJ_LINK_SIZE;
+    for (int k = 0; k < 3; k++) r[FMJ_LINK_URDF_POS + k] = xpos[3 * b + k] / meters;       /* :451-454 */
+    const double* q = xquat + 4 * b;                                                           /* :455-458 wxyz->xyzw */
+    r[FMJ_LINK_URDF_QUAT + 0] = q[1]; r[FMJ_LINK_URDF_QUAT + 1] = q[2]; r[FMJ_LINK_URDF_QUAT + 2] = q[3]; r[FMJ_LINK_URDF_QUAT + 3] = q[0];
+    for (int k = 0; k < 3; k++) r[FMJ_LINK_COM_POS + k] = xipos[3 * b + k] / meters;        /* :459-462 */
+    r[FMJ_LINK_COM_QUAT + 0] = q[1]; r[FMJ_LINK_COM_QUAT + 1] = q[2]; r[FMJ_LINK_COM_QUAT + 2] = q[3]; r[FMJ_LINK_COM_QUAT + 3] = q[0];  /* :463-466 */
+    const double* s = sd + lin_adr + 6 * (b - 1);
+    for (int k = 0; k < 3; k++) r[FMJ_LINK_COM_LINVEL + k] = s[k] / velocity;               /* :437-440 */
+    for (int k = 0; k < 3; k++) r[FMJ_LINK_COM_ANGVEL + k] = s[3 + k] / angvel;             /* :441-446 */
+  }
+  if (links_only) return;
+  /* sensor index of each non-free joint */
+  for (int i = 0; i < n_joints; i++) {
+    int j = joints_jnt[i]; double* r = joints + (size_t)i * FMJ_JOINT_SIZE;
+    int sj = 0; for (int jj = 0; jj < j; jj++) sj += m->jnt_type[jj] != FMJ_JNT_FREE;
+    r[FMJ_JOINT_LIMIT_FORCE] = sd[jnt_adr + 3 * sj + 2] / torques;                           /* :484-487 */
+    r[FMJ_JOINT_POSITION] = qpos[m->jnt_qposadr[j]];                                         /* :502-504 */
+    r[FMJ_JOINT_VELOCITY] = qvel[m->jnt_dofadr[j]] / angvel;                                 /* :505-507 */
+    /* motor torque: sum of the joint's actuatorfrc sensors (:510-524); written with '=' on a
+       fresh row */
+    double t = 0;
+    for (int a = 0; a < m->nu; a++) if (m->actuator_jntid[a] == j) t += sd[act_adr + a] * (1.0 / torques);
+    r[FMJ_JOINT_TORQUE] = t;
+  }
+}
+
+int fmjo_physics2data(const fmj_model* m, int n_envs, const double* qpos, const double* qvel,
+                      const double* xpos, const double* xquat, const double* xipos, const double* sensordata,
+                      int nsensordata, int n_links, const int32_t* links_body, int n_joints, const int32_t* joints_jnt,
+                      const double* units, int links_only, double* links, double* joints) {
+  for (int e = 0; e < n_envs; e++)
+    physics2data_one(m, qpos + (size_t)e * m->nq, qvel + (size_t)e * m->nv, xpos + (size_t)e * m->nbody * 3,
+                     xquat + (size_t)e * m->nbody * 4, xipos + (size_t)e * m->nbody * 3,
+                     sensordata + (size_t)e * nsensordata, n_links, links_body, n_joints, joints_jnt, units,
+                     links_only, links + (size_t)e * n_links * FMJ_LINK_SIZE,
+                     joints ? joints + (size_t)e * n_joints * FMJ_JOINT_SIZE : NULL);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* public: batched step                                                                         */
+
+typedef struct step_job {
+  const fmj_model* m; int e0, e1, n_steps; int64_t ctrl_step_stride;
+  double *qpos, *qvel; const double *ctrl, *qpos_spring, *xfrc;
+  double *xpos, *xquat, *xipos, *sensordata, *qacc; int32_t* status; int nsd; double meaninertia;
+} step_job;
+
+static int nsensordata(const fmj_model* m) {
+  int njs = 0; for (int j = 0; j < m->njnt; j++) njs += m->jnt_type[j] != FMJ_JNT_FREE;
+  return 6 * (m->nbody - 1) + 3 * njs + m->nu;
+}
+
+static void* step_worker(void* arg) {
+  step_job* J = (step_job*)arg; const fmj_model* m = J->m;
+  ws_t* w = ws_new(m); w->meaninertia = J->meaninertia;
+  double* sd = dalloc(J->nsd);
+  for (int e = J->e0; e < J->e1; e++) {
+    memset(w->qacc_warmstart, 0, m->nv * sizeof(double));
+    int warn = 0;
+    for (int s = 0; s < J->n_steps; s++) {
+      const double* ctrl = J->ctrl ? J->ctrl + (size_t)s * J->ctrl_step_stride + (size_t)e * m->nu : NULL;
+      warn |= step_one(m, w, J->qpos + (size_t)e * m->nq, J->qvel + (size_t)e * m->nv, ctrl,
+                       J->qpos_spring + (size_t)e * m->nq, J->xfrc ? J->xfrc + (size_t)e * m->nbody * 6 : NULL, sd);
+    }
+    if (J->xpos) memcpy(J->xpos + (size_t)e * m->nbody * 3, w->xpos, 3 * m->nbody * sizeof(double));
+    if (J->xquat) memcpy(J->xquat + (size_t)e * m->nbody * 4, w->xquat, 4 * m->nbody * sizeof(double));
+    if (J->xipos) memcpy(J->xipos + (size_t)e * m->nbody * 3, w->xipos, 3 * m->nbody * sizeof(double));
+    if (J->sensordata) memcpy(J->sensordata + (size_t)e * J->nsd, sd, J->nsd * sizeof(double));
+    if (J->qacc) memcpy(J->qacc + (size_t)e * m->nv, w->qacc, m->nv * sizeof(double));
+    if (J->status) J->status[e] |= warn;
+  }
+  free(sd); ws_free(w);
+  return NULL;
+}
+
+int fmjo_nsensordata(const fmj_model* m) { return nsensordata(m); }
+
+/* mj_step x n_steps for n_envs (batch-first fp64 arrays), n_threads pthreads over env ranges. */
+int fmjo_step(const fmj_model* m, int n_envs, int n_steps, int64_t ctrl_step_stride,
+              double* qpos, double* qvel, const double* ctrl, const double* qpos_spring, const double* xfrc_applied,
+              double* xpos, double* xquat, double* xipos, double* sensordata, double* qacc, int32_t* status,
+              int n_threads) {
+  if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_envs) n_threads = n_envs;
+  double mi = mean_inertia(m);
+  pthread_t* th = (pthread_t*)malloc(n_threads * sizeof(pthread_t));
+  step_job* jobs = (step_job*)malloc(n_threads * sizeof(step_job));
+  for (int t = 0; t < n_threads; t++) {
+    step_job J = {m, (int)((int64_t)n_envs * t / n_threads), (int)((int64_t)n_envs * (t + 1) / n_threads), n_steps,
+                  ctrl_step_stride, qpos, qvel, ctrl, qpos_spring, xfrc_applied, xpos, xquat, xipos, sensordata, qacc,
+                  status, nsensordata(m), mi};
+    jobs[t] = J;
+    if (n_threads == 1) step_worker(&jobs[t]); else pthread_create(&th[t], NULL, step_worker, &jobs[t]);
+  }
+  if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  free(th); free(jobs);
+  return FMJ_OK;
+}
+
+/* mj_forward internals for ONE env, for KATs: any output pointer may be NULL.
+ * Mdense [nv,nv] is the full symmetric joint-space inertia. */
+int fmjo_forward_debug(const fmj_model* m, const double* qpos, const double* qvel, const double* ctrl,
+                       const double* qpos_spring, const double* xfrc_applied,
+                       double* Mdense, double* qfrc_bias, double* qfrc_passive, double* qfrc_actuator,
+                       double* qfrc_xfrc, double* qfrc_smooth, double* qacc_smooth, double* qfrc_constraint,
+                       double* qacc, double* xpos, double* xquat, double* xipos, double* subtree_com,
+                       double* cvel, double* sensordata, int32_t* ncon_nefc, double* efc_force, double* contact_out) {
+  ws_t* w = ws_new(m); w->meaninertia = mean_inertia(m);
+  double* sd = dalloc(nsensordata(m));
+  forward(m, w, qpos, qvel, ctrl, qpos_spring, xfrc_applied, sd);
+  int nv = m->nv;
+  if (Mdense) {
+    memset(Mdense, 0, (size_t)nv * nv * sizeof(double));
+    for (int i = 0; i < nv; i++) { int a = m->dof_Madr[i]; for (int j = i; j >= 0; j = m->dof_parentid[j]) { Mdense[i * nv + j] = Mdense[j * nv + i] = w->qM[a++]; } }
+  }
+#define CP(dst, src, n) if (dst) memcpy(dst, src, (n) * sizeof(double))
+  CP(qfrc_bias, w->qfrc_bias, nv); CP(qfrc_passive, w->qfrc_passive, nv); CP(qfrc_actuator, w->qfrc_actuator, nv);
+  CP(qfrc_xfrc, w->qfrc_xfrc, nv); CP(qfrc_smooth, w->qfrc_smooth, nv); CP(qacc_smooth, w->qacc_smooth, nv);
+  CP(qfrc_constraint, w->qfrc_constraint, nv); CP(qacc, w->qacc, nv);
+  CP(xpos, w->xpos, 3 * m->nbody); CP(xquat, w->xquat, 4 * m->nbody); CP(xipos, w->xipos, 3 * m->nbody);
+  CP(subtree_com, w->subtree_com, 3 * m->nbody); CP(cvel, w->cvel, 6 * m->nbody);
+  CP(sensordata, sd, nsensordata(m));
+  if (ncon_nefc) { ncon_nefc[0] = w->ncon; ncon_nefc[1] = w->nefc; }
+  CP(efc_force, w->efc_force, w->nefc);
+  if (contact_out) for (int c = 0; c < w->ncon; c++) {  /* [ncon, 3 pos + 9 frame + dist + geom] */
+    double* o = contact_out + 14 * c;
+    memcpy(o, w->con_pos + 3 * c, 3 * sizeof(double)); memcpy(o + 3, w->con_frame + 9 * c, 9 * sizeof(double));
+    o[12] = w->con_dist[c]; o[13] = w->con_geom[c];
+  }
+#undef CP
+  free(sd); ws_free(w);
+  return FMJ_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fused loop: ExperimentTask.before_step + Environment.step (reference task.py:168-186,         */
+/* simulation.py:155-156): physics2data(row) -> drag -> xfrc glue -> ctrl -> mj_step             */
+
+typedef struct fused_job {
+  const fmj_model* m; int e0, e1, n_envs;
+  int n_steps, iteration0, buffer_size, do_readout, do_drag, controller; int64_t ctrl_step_stride;
+  double *qpos, *qvel; const double *ctrl, *qpos_spring;
+  double *xpos, *xquat, *xipos, *sensordata; int32_t* status;
+  double *links, *joints, *xfrc;   /* [buffer, n_envs, n, width] */
+  int n_links; const int32_t* links_body; int n_joints; const int32_t* joints_jnt;
+  int ns; const int32_t *sw_links_index, *sw_xfrc_index, *sw_body_index;
+  const double *coefficients, *masses, *heights, *densities;
+  double surface, water_vel[3], viscosity, gravity; int use_buoyancy;
+  const double* units;  /* meters,newtons,torques,velocity,angular_velocity */
+  const double *wave_amplitude, *wave_phase_lag, *wave_env_phase; double wave_frequency;
+  double meaninertia;
+} fused_job;
+
+static void* fused_worker(void* arg) {
+  fused_job* J = (fused_job*)arg; const fmj_model* m = J->m;
+  int nsd = nsensordata(m), nb = m->nbody;
+  ws_t* w = ws_new(m); w->meaninertia = J->meaninertia;
+  double* ctrl = dalloc(m->nu);
+  double* xa = dalloc(6 * nb);
+  double* tmp_links = dalloc((size_t)J->n_links * FMJ_LINK_SIZE);
+  for (int e = J->e0; e < J->e1; e++) {
+    double* qpos = J->qpos + (size_t)e * m->nq; double* qvel = J->qvel + (size_t)e * m->nv;
+    double* xpos = J->xpos + (size_t)e * nb * 3; double* xquat = J->xquat + (size_t)e * nb * 4;
+    double* xipos = J->xipos + (size_t)e * nb * 3; double* sd = J->sensordata + (size_t)e * nsd;
+    memset(w->qacc_warmstart, 0, m->nv * sizeof(double));
+    memset(xa, 0, 6 * nb * sizeof(double));
+    int warn = 0;
+    for (int s = 0; s < J->n_steps; s++) {
+      int it = J->iteration0 + s, index = it % J->buffer_size;
+      double* lrow = tmp_links;
+      if (J->do_readout) {
+        lrow = J->links + ((size_t)index * J->n_envs + e) * J->n_links * FMJ_LINK_SIZE;
+        double* jrow = J->joints + ((size_t)index * J->n_envs + e) * J->n_joints * FMJ_JOINT_SIZE;
+        physics2data_one(m, qpos, qvel, xpos, xquat, xipos, sd, J->n_links, J->links_body, J->n_joints,
+                         J->joints_jnt, J->units, 0, lrow, jrow);
+      } else if (J->do_drag) {
+        physics2data_one(m, qpos, qvel, xpos, xquat, xipos, sd, J->n_links, J->links_body, 0, NULL, J->units, 1, lrow, NULL);
+      }
+      if (J->do_drag) {
+        double* xrow = J->xfrc + ((size_t)index * J->n_envs + e) * J->n_links * FMJ_XFRC_SIZE;
+        fmjo_drag(1, J->n_links, J->n_links, nb, J->ns, J->sw_links_index, J->sw_xfrc_index, J->sw_body_index,
+                  J->coefficients, J->masses, J->heights, J->densities, J->surface, J->water_vel, J->viscosity,
+                  J->gravity, J->use_buoyancy, J->units[1], J->units[2], lrow, xrow, xa);
+      }
+      if (J->controller == 1) {
+        double t = it * m->timestep;   /* task.py:290 */
+        for (int a = 0; a < m->nu; a++)
+          ctrl[a] = J->wave_amplitude[a] * sin(2 * M_PI * J->wave_frequency * t - J->wave_phase_lag[a] + J->wave_env_phase[e]);
+      } else if (J->ctrl) {
+        memcpy(ctrl, J->ctrl + (size_t)s * J->ctrl_step_stride + (size_t)e * m->nu, m->nu * sizeof(double));
+      }
+      warn |= step_one(m, w, qpos, qvel, ctrl, J->qpos_spring + (size_t)e * m->nq, J->do_drag ? xa : NULL, sd);
+      memcpy(xpos, w->xpos, 3 * nb * sizeof(double)); memcpy(xquat, w->xquat, 4 * nb * sizeof(double));
+      memcpy(xipos, w->xipos, 3 * nb * sizeof(double));
+    }
+    if (J->status) J->status[e] |= warn;
+  }
+  free(ctrl); free(xa); free(tmp_links); ws_free(w);
+  return NULL;
+}
+
+int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, int buffer_size,
+                   int do_readout, int do_drag, int controller, int64_t ctrl_step_stride,
+                   double* qpos, double* qvel, const double* ctrl, const double* qpos_spring,
+                   double* xpos, double* xquat, double* xipos, double* sensordata, int32_t* status,
+                   double* links, double* joints, double* xfrc,
+                   int n_links, const int32_t* links_body, int n_joints, const int32_t* joints_jnt,
+                   int ns, const int32_t* sw_links_index, const int32_t* sw_xfrc_index, const int32_t* sw_body_index,
+                   const double* coefficients, const double* masses, const double* heights, const double* densities,
+                   double surface, const double* water_vel, double viscosity, double gravity, int use_buoyancy,
+                   const double* units, const double* wave_amplitude, const double* wave_phase_lag,
+                   const double* wave_env_phase, double wave_frequency, int n_threads) {
+  if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
+  if (n_threads < 1) n_threads = 1;
+  if (n_threads > n_envs) n_threads = n_envs;
+  double mi = mean_inertia(m);
+  pthread_t* th = (pthread_t*)malloc(n_threads * sizeof(pthread_t));
+  fused_job* jobs = (fused_job*)calloc(n_threads, sizeof(fused_job));
+  for (int t = 0; t < n_threads; t++) {
+    fused_job* J = &jobs[t];
+    J->m = m; J->e0 = (int)((int64_t)n_envs * t / n_threads); J->e1 = (int)((int64_t)n_envs * (t + 1) / n_threads);
+    J->n_envs = n_envs; J->n_steps = n_steps; J->iteration0 = iteration0; J->buffer_size = buffer_size;
+    J->do_readout = do_readout; J->do_drag = do_drag; J->controller = controller; J->ctrl_step_stride = ctrl_step_stride;
+    J->qpos = qpos; J->qvel = qvel; J->ctrl = ctrl; J->qpos_spring = qpos_spring;
+    J->xpos = xpos; J->xquat = xquat; J->xipos = xipos; J->sensordata = sensordata; J->status = status;
+    J->links = links; J->joints = joints; J->xfrc = xfrc;
+    J->n_links = n_links; J->links_body = links_body; J->n_joints = n_joints; J->joints_jnt = joints_jnt;
+    J->ns = ns; J->sw_links_index = sw_links_index; J->sw_xfrc_index = sw_xfrc_index; J->sw_body_index = sw_body_index;
+    J->coefficients = coefficients; J->masses = masses; J->heights = heights; J->densities = densities;
+    J->surface = surface; if (water_vel) memcpy(J->water_vel, water_vel, sizeof J->water_vel);
+    J->viscosity = viscosity; J->gravity = gravity; J->use_buoyancy = use_buoyancy; J->units = units;
+    J->wave_amplitude = wave_amplitude; J->wave_phase_lag = wave_phase_lag; J->wave_env_phase = wave_env_phase;
+    J->wave_frequency = wave_frequency; J->meaninertia = mi;
+    if (n_threads == 1) fused_worker(J); else pthread_create(&th[t], NULL, fused_worker, J);
+  }
+  if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
+  free(th); free(jobs);
+  return FMJ_OK;
+}

@@ -1,0 +1,182 @@
+"""ctypes front-end of oracle/fmj_oracle.c — TEST INFRASTRUCTURE ONLY.
+
+Only tests/, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this.
+PARITY UNPINNED versus MuJoCo (see the header of fmj_oracle.c).
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, '_build', 'libfmj_oracle.so')
+_lib = None
+
+_D = ctypes.POINTER(ctypes.c_double)
+_I = ctypes.POINTER(ctypes.c_int32)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, 'fmj_oracle.c')
+    hdr = os.path.join(_HERE, '..', 'include', 'fmj.h')
+    if (force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
+            or os.path.getmtime(_SO) < os.path.getmtime(hdr)):
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'])
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        _lib = ctypes.CDLL(_SO)
+    return _lib
+
+
+def _d(a):
+    return None if a is None else a.ctypes.data_as(_D)
+
+
+def _i(a):
+    return None if a is None else a.ctypes.data_as(_I)
+
+
+def _c64(a, shape=None):
+    a = np.ascontiguousarray(a, np.float64)
+    if shape is not None:
+        a = a.reshape(shape)
+    return a
+
+
+def step(model, qpos, qvel, ctrl=None, qpos_spring=None, xfrc_applied=None, n_steps=1,
+         ctrl_step_stride=0, n_threads=1):
+    """mj_step x n_steps on batch-first fp64 arrays. Returns dict with new state + derived."""
+    m = model
+    c = m.as_c()
+    qpos = _c64(qpos).reshape(-1, m.nq).copy()
+    n = qpos.shape[0]
+    qvel = _c64(qvel).reshape(n, m.nv).copy()
+    ctrl = None if ctrl is None else _c64(ctrl)
+    qs = _c64(np.broadcast_to(m.qpos_spring, (n, m.nq)) if qpos_spring is None else qpos_spring).copy()
+    xf = None if xfrc_applied is None else _c64(xfrc_applied).reshape(n, m.nbody, 6)
+    nsd = m.nsensordata
+    out = dict(xpos=np.zeros((n, m.nbody, 3)), xquat=np.zeros((n, m.nbody, 4)), xipos=np.zeros((n, m.nbody, 3)),
+               sensordata=np.zeros((n, nsd)), qacc=np.zeros((n, m.nv)), status=np.zeros(n, np.int32))
+    rc = lib().fmjo_step(ctypes.byref(c), n, int(n_steps), ctypes.c_int64(int(ctrl_step_stride)), _d(qpos), _d(qvel),
+                         _d(ctrl), _d(qs), _d(xf), _d(out['xpos']), _d(out['xquat']), _d(out['xipos']),
+                         _d(out['sensordata']), _d(out['qacc']), _i(out['status']), int(n_threads))
+    assert rc == 0, rc
+    out['qpos'] = qpos
+    out['qvel'] = qvel
+    return out
+
+
+def forward_debug(model, qpos, qvel, ctrl=None, qpos_spring=None, xfrc_applied=None):
+    m = model
+    c = m.as_c()
+    nv, nb = m.nv, m.nbody
+    qpos = _c64(qpos); qvel = _c64(qvel)
+    ctrl = None if ctrl is None else _c64(ctrl)
+    qs = _c64(m.qpos_spring if qpos_spring is None else qpos_spring)
+    xf = None if xfrc_applied is None else _c64(xfrc_applied)
+    maxefc = 2*m.njnt + 4*max(m.max_contacts, 0)
+    o = dict(M=np.zeros((nv, nv)), qfrc_bias=np.zeros(nv), qfrc_passive=np.zeros(nv), qfrc_actuator=np.zeros(nv),
+             qfrc_xfrc=np.zeros(nv), qfrc_smooth=np.zeros(nv), qacc_smooth=np.zeros(nv),
+             qfrc_constraint=np.zeros(nv), qacc=np.zeros(nv), xpos=np.zeros((nb, 3)), xquat=np.zeros((nb, 4)),
+             xipos=np.zeros((nb, 3)), subtree_com=np.zeros((nb, 3)), cvel=np.zeros((nb, 6)),
+             sensordata=np.zeros(m.nsensordata), counts=np.zeros(2, np.int32), efc_force=np.zeros(max(maxefc, 1)),
+             contact=np.zeros((max(m.max_contacts, 1), 14)))
+    rc = lib().fmjo_forward_debug(ctypes.byref(c), _d(qpos), _d(qvel), _d(ctrl), _d(qs), _d(xf), _d(o['M']),
+                                  _d(o['qfrc_bias']), _d(o['qfrc_passive']), _d(o['qfrc_actuator']),
+                                  _d(o['qfrc_xfrc']), _d(o['qfrc_smooth']), _d(o['qacc_smooth']),
+                                  _d(o['qfrc_constraint']), _d(o['qacc']), _d(o['xpos']), _d(o['xquat']),
+                                  _d(o['xipos']), _d(o['subtree_com']), _d(o['cvel']), _d(o['sensordata']),
+                                  _i(o['counts']), _d(o['efc_force']), _d(o['contact']))
+    assert rc == 0, rc
+    o['ncon'], o['nefc'] = int(o['counts'][0]), int(o['counts'][1])
+    return o
+
+
+def _swim_arrays(swim):
+    """swim: dict from farms_mujoco_amd swimming setup (links_index, xfrc_index, body_index, coefficients, ...)."""
+    return (np.ascontiguousarray(swim['links_index'], np.int32), np.ascontiguousarray(swim['xfrc_index'], np.int32),
+            np.ascontiguousarray(swim['body_index'], np.int32), _c64(swim['coefficients']), _c64(swim['masses']),
+            _c64(swim['heights']), _c64(swim['densities']))
+
+
+def drag(swim, water, links, xfrc, nbody, units=(1.0, 1.0), want_applied=True):
+    """SwimmingHandler.step on batch-first fp64 rows. links [n, n_links, 20]; xfrc [n, n_xfrc, 6] updated in place
+    (returned). water: dict(surface, velocity, viscosity, gravity, use_buoyancy)."""
+    links = _c64(links); xfrc = _c64(xfrc).copy()
+    n = links.shape[0]
+    li, xi, bi, co, ma, he, de = _swim_arrays(swim)
+    xa = np.zeros((n, nbody, 6)) if want_applied else None
+    wv = _c64(water['velocity'])
+    rc = lib().fmjo_drag(n, links.shape[1], xfrc.shape[1], int(nbody), len(li), _i(li), _i(xi), _i(bi), _d(co), _d(ma),
+                         _d(he), _d(de), ctypes.c_double(water['surface']), _d(wv), ctypes.c_double(water['viscosity']),
+                         ctypes.c_double(water.get('gravity', -9.81)), int(water['use_buoyancy']),
+                         ctypes.c_double(units[0]), ctypes.c_double(units[1]), _d(links), _d(xfrc), _d(xa))
+    assert rc == 0
+    return xfrc, xa
+
+
+def physics2data(model, qpos, qvel, xpos, xquat, xipos, sensordata, links_body, joints_jnt,
+                 units=(1.0, 1.0, 1.0, 1.0, 1.0), links_only=False):
+    m = model
+    c = m.as_c()
+    qpos = _c64(qpos).reshape(-1, m.nq); n = qpos.shape[0]
+    lb = np.ascontiguousarray(links_body, np.int32); jj = np.ascontiguousarray(joints_jnt, np.int32)
+    links = np.zeros((n, len(lb), 20)); joints = np.zeros((n, len(jj), 12))
+    u = _c64(units)
+    rc = lib().fmjo_physics2data(ctypes.byref(c), n, _d(qpos), _d(_c64(qvel)), _d(_c64(xpos)), _d(_c64(xquat)),
+                                 _d(_c64(xipos)), _d(_c64(sensordata)), m.nsensordata, len(lb), _i(lb), len(jj), _i(jj),
+                                 _d(u), int(links_only), _d(links), _d(joints))
+    assert rc == 0
+    return links, joints
+
+
+def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer_size=1, do_readout=True,
+              do_drag=True, controller=0, ctrl=None, ctrl_step_stride=0, wave=None, links_body=None,
+              joints_jnt=None, units=(1.0, 1.0, 1.0, 1.0, 1.0), n_threads=1):
+    """The fused loop (readout -> drag -> ctrl -> mj_step) x n_steps.  ``state`` = dict(qpos, qvel, xpos, xquat,
+    xipos, sensordata[, qpos_spring]) batch-first; returns new state + ring-buffer rows."""
+    m = model
+    c = m.as_c()
+    qpos = _c64(state['qpos']).reshape(-1, m.nq).copy(); n = qpos.shape[0]
+    qvel = _c64(state['qvel']).reshape(n, m.nv).copy()
+    xpos = _c64(state['xpos']).reshape(n, m.nbody, 3).copy(); xquat = _c64(state['xquat']).reshape(n, m.nbody, 4).copy()
+    xipos = _c64(state['xipos']).reshape(n, m.nbody, 3).copy()
+    sd = _c64(state['sensordata']).reshape(n, m.nsensordata).copy()
+    qs = _c64(np.broadcast_to(m.qpos_spring, (n, m.nq)) if state.get('qpos_spring') is None else state['qpos_spring']).copy()
+    status = np.zeros(n, np.int32)
+    lb = np.ascontiguousarray(np.arange(1, m.nbody) if links_body is None else links_body, np.int32)
+    jj = np.ascontiguousarray(np.nonzero(m.jnt_type != 0)[0] if joints_jnt is None else joints_jnt, np.int32)
+    links = np.zeros((buffer_size, n, len(lb), 20)); joints = np.zeros((buffer_size, n, len(jj), 12))
+    xfrc = np.zeros((buffer_size, n, len(lb), 6))
+    if swim is not None:
+        li, xi, bi, co, ma, he, de = _swim_arrays(swim)
+    else:
+        li = xi = bi = np.zeros(1, np.int32); co = ma = he = de = np.zeros(6)
+        do_drag = False
+    water = water or dict(surface=0.0, velocity=[0, 0, 0], viscosity=1.0, gravity=-9.81, use_buoyancy=True)
+    wv = _c64(water['velocity'])
+    ctrl = None if ctrl is None else _c64(ctrl)
+    if wave is not None:
+        wa, wp, we = _c64(wave['amplitude']), _c64(wave['phase_lag']), _c64(wave['env_phase'])
+        wf = float(wave['frequency'])
+    else:
+        wa = wp = we = None; wf = 0.0
+    u = _c64(units)
+    rc = lib().fmjo_run_fused(ctypes.byref(c), n, int(n_steps), int(iteration0), int(buffer_size), int(do_readout),
+                              int(do_drag), int(controller), ctypes.c_int64(int(ctrl_step_stride)), _d(qpos), _d(qvel),
+                              _d(ctrl), _d(qs), _d(xpos), _d(xquat), _d(xipos), _d(sd), _i(status), _d(links), _d(joints),
+                              _d(xfrc), len(lb), _i(lb), len(jj), _i(jj), len(li) if swim is not None else 0, _i(li),
+                              _i(xi), _i(bi), _d(co), _d(ma), _d(he), _d(de), ctypes.c_double(water['surface']), _d(wv),
+                              ctypes.c_double(water['viscosity']), ctypes.c_double(water.get('gravity', -9.81)),
+                              int(water['use_buoyancy']), _d(u), _d(wa), _d(wp), _d(we), ctypes.c_double(wf),
+                              int(n_threads))
+    assert rc == 0, rc
+    return dict(qpos=qpos, qvel=qvel, xpos=xpos, xquat=xquat, xipos=xipos, sensordata=sd, status=status,
+                links=links, joints=joints, xfrc=xfrc)
