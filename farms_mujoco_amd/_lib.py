@@ -1,0 +1,125 @@
+"""ctypes binding of the C-ABI in include/fmj.h (libfmj_hip.so, built in-tree by :func:`build`).
+
+There is no CPU fallback: if the shared library is missing or no GPU is visible the product path
+raises.  Loading the library and looking up its symbols does not need a GPU.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, 'csrc')
+SO_PATH = os.path.join(CSRC, 'libfmj_hip.so')
+HEADER = os.path.join(_HERE, '..', 'include', 'fmj.h')
+
+_F = ctypes.POINTER(ctypes.c_float)
+_I = ctypes.POINTER(ctypes.c_int32)
+_D = ctypes.POINTER(ctypes.c_double)
+_VP = ctypes.c_void_p
+
+
+class FmjError(RuntimeError):
+    """Non-zero status from the C-ABI (message from fmj_last_error)."""
+
+
+class CData(ctypes.Structure):
+    _fields_ = [(n, _VP) for n in ('qpos', 'qvel', 'ctrl', 'qpos_spring', 'xfrc_applied', 'xpos', 'xquat',
+                                   'xipos', 'sensordata', 'qacc', 'time', 'status')]
+
+
+class CSensorLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('nsensordata', 'framelinvel_adr', 'jointpos_adr',
+                                              'actuatorfrc_adr', 'first_link_body', 'first_sensor_jnt')]
+
+
+class CRows(ctypes.Structure):
+    _fields_ = [(n, _VP) for n in ('links', 'joints', 'xfrc', 'contacts')]
+
+
+class CUnits(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_float) for n in ('meters', 'newtons', 'torques', 'velocity', 'angular_velocity',
+                                              'kilograms')]
+
+
+class CWater(ctypes.Structure):
+    _fields_ = [('surface', ctypes.c_float), ('density', ctypes.c_float), ('viscosity', ctypes.c_float),
+                ('velocity', ctypes.c_float*3), ('gravity', ctypes.c_float), ('use_buoyancy', ctypes.c_int32)]
+
+
+class CWave(ctypes.Structure):
+    _fields_ = [('amplitude', _VP), ('phase_lag', _VP), ('env_phase', _VP), ('frequency', ctypes.c_float)]
+
+
+class CFusedArgs(ctypes.Structure):
+    _fields_ = [('n_steps', ctypes.c_int32), ('iteration0', ctypes.c_int32), ('buffer_size', ctypes.c_int32),
+                ('do_readout', ctypes.c_int32), ('do_drag', ctypes.c_int32), ('controller', ctypes.c_int32),
+                ('ctrl_step_stride', ctypes.c_int64), ('row_stride_links', ctypes.c_int64),
+                ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
+                ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave)]
+
+
+# every symbol include/fmj.h declares: name -> (restype, argtypes)
+SYMBOLS = {
+    'fmj_create': (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_VP)]),
+    'fmj_destroy': (None, [_VP]),
+    'fmj_last_error': (ctypes.c_char_p, []),
+    'fmj_abi_version': (ctypes.c_int, []),
+    'fmj_get_sensor_layout': (ctypes.c_int, [_VP, ctypes.POINTER(CSensorLayout)]),
+    'fmj_kernel_info': (ctypes.c_int, [_VP, _I, _I]),
+    'fmj_set_swimming': (ctypes.c_int, [_VP, ctypes.c_int32, _I, _I, _I, _D, _D, _D, _D]),
+    'fmj_set_readout_maps': (ctypes.c_int, [_VP, ctypes.c_int32, _I, ctypes.c_int32, _I]),
+    'fmj_step': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, ctypes.c_int64, _VP]),
+    'fmj_forward': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP]),
+    'fmj_drag': (ctypes.c_int, [_VP, ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits), _VP, _VP]),
+    'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
+                                        ctypes.c_int32, _VP]),
+    'fmj_step_fused': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CFusedArgs), _VP]),
+    'fmj_sc': (ctypes.c_int, [ctypes.c_char_p]),
+}
+
+_lib = None
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """Compile csrc/fmj_hip.hip for gfx950 into csrc/libfmj_hip.so (hipcc cross-compiles without a GPU)."""
+    src = os.path.join(CSRC, 'fmj_hip.hip')
+    stale = (not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src)
+             or os.path.getmtime(SO_PATH) < os.path.getmtime(HEADER))
+    if force or stale:
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fPIC', '-shared', src, '-o', SO_PATH]
+        if verbose:
+            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
+        subprocess.check_call(cmd)
+    return SO_PATH
+
+
+def load():
+    """dlopen the HIP library and bind every declared symbol. Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(SO_PATH):
+        raise FmjError(f'{SO_PATH} is missing: the HIP extension is not built. Run '
+                       '`python -c "import __graft_entry__ as g; g.build()"` (needs hipcc). '
+                       'There is no CPU fallback for the product path.')
+    lib = ctypes.CDLL(SO_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    if lib.fmj_abi_version() != 1:
+        raise FmjError('libfmj_hip.so ABI version mismatch; rebuild')
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        raise FmjError(f'fmj status {rc}: {load().fmj_last_error().decode()}')
+
+
+def sc(name: str) -> int:
+    v = load().fmj_sc(name.encode())
+    if v < 0:
+        raise KeyError(name)
+    return v

@@ -1,0 +1,1181 @@
+// fmj_hip.hip — MI355X (gfx950) implementation of include/fmj.h.
+//
+// One wavefront (64 lanes) owns one environment.  Lanes play two roles, "lane = body" and
+// "lane = dof"; cross-lane data goes through LDS, everything else stays in registers.  There is
+// no MFMA: the largest "matrix" is the nv x nv (<= 64) tree-sparse joint-space inertia.
+//
+// Per step (mj_step semantics, MuJoCo's documented pipeline restricted to what reference
+// farms_mujoco/simulation/mjcf.py emits):
+//   K  local joint transforms (lane=body) -> LDS; every lane composes its root->body chain
+//   C  subtree CoM by wave reduction; cinert (lane=body), cdof (lane=body -> dof slots)
+//   V  per-body joint velocity vJ -> LDS; every lane walks its chain: cvel, cacc (no cdof_dot
+//      array: cdof_dot*qvel = cvel_parent x vJ by linearity of the motion cross product)
+//   F  body force f = I a + v x* I v - F_ext (lane=body) -> LDS
+//   S  subtree sums over the contiguous DFS id range: composite inertia, accumulated force
+//   Q  qfrc_smooth (lane=dof): passive + actuation - cdof . f_subtree
+//   M  H = M + diag(armature + h*damping): one entry per lane-round, depth-indexed rows in LDS
+//   L  L'DL: lane i owns row i in registers; step k broadcasts row k through LDS
+//   X  two triangular sweeps with v_readlane broadcasts; semi-implicit Euler; sensors
+//
+// Fused mode wraps this with the reference's before_step work (task.py:168-186):
+// physics2data row write (physics.py:527-545), SwimmingHandler.step (drag.pyx:389-411) and the
+// xfrc_applied glue, and the ctrl write (task.py:288-346), looping n_steps inside one launch.
+
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/fmj.h"
+
+#define FMJ_MAX_LANES 64
+#define FMJ_MAXD 32         // max dof-chain length (register row length)
+#define FMJ_MAXBD 32        // max body-chain length
+
+static thread_local std::string g_err;
+static int set_err(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_TRY(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) return set_err(FMJ_ERR_HIP, std::string(#x) + ": " + hipGetErrorString(e_)); } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// device model (fp32 tables shared by all envs)
+
+struct DevModel {
+  int nbody, nv, nq, nu, njnt, nM, nMpad;
+  int max_bdepth;     // longest root->body chain (bodies, incl. self)
+  int max_subsize;    // largest subtree (bodies)
+  int rs;             // row stride of Hrow (multiple of 4, >= max dof depth + 1)
+  int root_free;      // 1 if body 1 carries a free joint
+  int any_stiffness, nsensordata, njs;
+  int n_links, n_joints, n_xfrc, ns;
+  int anc_stride;     // bytes per chain row (multiple of 4)
+  float h, gx, gy, gz, mtot_inv;
+  // per body [64]
+  const float4* b_pos_mass;   // body_pos xyz, mass
+  const float4* b_quat;
+  const float4* b_ipos;
+  const float4* b_iquat;
+  const float4* b_inertia;
+  const float4* j_axis_q0;    // joint axis xyz, qpos0 of the joint coordinate
+  const float4* j_pos_k;      // joint pos xyz, stiffness
+  const int4* b_info;         // parent, jnt type (-1 none), qposadr, dofadr
+  const int4* b_info2;        // depth (chain length-1), subtree size, link row (-1), swim slot (-1)
+  const uint8_t* b_anc;       // [nbody][anc_stride] root-first chain incl. self
+  // per dof [64]
+  const int4* d_info;         // body, depth, subtree size (dofs), joint row (-1)
+  const float4* d_prm;        // armature, damping, qposadr(as float bits), is_hinge_or_slide
+  const int4* d_act;          // first actuator, count (actuators sorted by dof), joint-sensor slot, -
+  // actuators [nu] sorted by dof; a_src = original actuator index
+  const float4* a_prm;        // gain, bias0, bias1, bias2
+  const float4* a_lim;        // ctrl lo, ctrl hi, force lo, force hi (+-FLT_MAX when unlimited)
+  const int* a_src;
+  // M entries [nMpad]: i | j<<8 | depth<<16 | valid<<24 ; m_add = armature + h*damping on the diagonal
+  const uint32_t* m_tab;
+  const float* m_add;
+  // swimming [ns]: coeff(6), mass, height, density -> 3 float4
+  const float4* s_c0;         // clin xyz, mass
+  const float4* s_c1;         // cang xyz, height
+  const float4* s_c2;         // density, links_index, xfrc_index, body
+};
+
+struct StepArgs {
+  float* qpos; float* qvel; const float* ctrl; const float* qpos_spring; const float* xfrc_applied;
+  float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
+  int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
+  long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc;
+  float* links; float* joints; float* xfrc; float* xfrc_applied_out;
+  // water / units
+  float surface, viscosity, wvx, wvy, wvz, wgravity; int use_buoyancy;
+  float inv_meters, inv_velocity, inv_angvel, inv_torques, newtons, torques;
+  // wave controller
+  const float* w_amp; const float* w_lag; const float* w_env; float w_freq;
+};
+
+struct fmj_ctx {
+  int device, n_envs;
+  DevModel dm;
+  std::vector<void*> allocs;
+  size_t lds_bytes;
+  fmj_sensor_layout_t layout;
+  // host copies needed later
+  std::vector<int> body_link_row, dof_joint_row, body_swim;
+  std::vector<int> h_b_info2;     // mutable table mirror
+  std::vector<int> h_d_info;
+  int4* d_b_info2; int4* d_d_info;
+  int nbody, nv, nu, njnt;
+  std::vector<int> jnt_dofadr, jnt_type;
+};
+
+// ---------------------------------------------------------------------------------------------
+// device math
+
+struct v3 { float x, y, z; };
+struct q4 { float w, x, y, z; };
+
+__device__ __forceinline__ v3 mk3(float x, float y, float z) { v3 r = {x, y, z}; return r; }
+__device__ __forceinline__ v3 add3(v3 a, v3 b) { return mk3(a.x + b.x, a.y + b.y, a.z + b.z); }
+__device__ __forceinline__ v3 sub3(v3 a, v3 b) { return mk3(a.x - b.x, a.y - b.y, a.z - b.z); }
+__device__ __forceinline__ v3 scl3(v3 a, float s) { return mk3(a.x * s, a.y * s, a.z * s); }
+__device__ __forceinline__ float dot3(v3 a, v3 b) { return fmaf(a.x, b.x, fmaf(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ v3 cross(v3 a, v3 b) {
+  return mk3(a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x);
+}
+__device__ __forceinline__ q4 qmul(q4 a, q4 b) {
+  q4 r;
+  r.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  r.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  r.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  r.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  return r;
+}
+// v' = q v q*  via t = 2 qv x v ; v' = v + w t + qv x t
+__device__ __forceinline__ v3 qrot(q4 q, v3 v) {
+  v3 qv = mk3(q.x, q.y, q.z);
+  v3 t = scl3(cross(qv, v), 2.0f);
+  return add3(add3(v, scl3(t, q.w)), cross(qv, t));
+}
+__device__ __forceinline__ q4 qnormalize(q4 q) {
+  float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
+  if (n2 < 1e-30f) { q4 r = {1.f, 0.f, 0.f, 0.f}; return r; }
+  float inv = 1.0f / sqrtf(n2);
+  q4 r = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+  return r;
+}
+__device__ __forceinline__ q4 axisangle(v3 ax, float ang) {
+  float s, c;
+  sincosf(0.5f * ang, &s, &c);
+  q4 r = {c, ax.x * s, ax.y * s, ax.z * s};
+  return r;
+}
+struct m33 { float a[9]; };
+__device__ __forceinline__ m33 q2m(q4 q) {
+  m33 m;
+  float q00 = q.w * q.w, q11 = q.x * q.x, q22 = q.y * q.y, q33 = q.z * q.z;
+  m.a[0] = q00 + q11 - q22 - q33; m.a[4] = q00 - q11 + q22 - q33; m.a[8] = q00 - q11 - q22 + q33;
+  m.a[1] = 2.f * (q.x * q.y - q.w * q.z); m.a[2] = 2.f * (q.x * q.z + q.w * q.y);
+  m.a[3] = 2.f * (q.x * q.y + q.w * q.z); m.a[5] = 2.f * (q.y * q.z - q.w * q.x);
+  m.a[6] = 2.f * (q.x * q.z - q.w * q.y); m.a[7] = 2.f * (q.y * q.z + q.w * q.x);
+  return m;
+}
+__device__ __forceinline__ v3 mrot(const m33& m, v3 v) {
+  return mk3(fmaf(m.a[0], v.x, fmaf(m.a[1], v.y, m.a[2] * v.z)),
+             fmaf(m.a[3], v.x, fmaf(m.a[4], v.y, m.a[5] * v.z)),
+             fmaf(m.a[6], v.x, fmaf(m.a[7], v.y, m.a[8] * v.z)));
+}
+// spatial vectors: [rot; lin]
+struct s6 { v3 r, l; };
+__device__ __forceinline__ s6 s6add(s6 a, s6 b) { s6 o = {add3(a.r, b.r), add3(a.l, b.l)}; return o; }
+__device__ __forceinline__ s6 s6scl(s6 a, float s) { s6 o = {scl3(a.r, s), scl3(a.l, s)}; return o; }
+__device__ __forceinline__ float s6dot(s6 a, s6 b) { return dot3(a.r, b.r) + dot3(a.l, b.l); }
+// motion cross  vel x v
+__device__ __forceinline__ s6 cross_motion(s6 vel, s6 v) {
+  s6 o = {cross(vel.r, v.r), add3(cross(vel.r, v.l), cross(vel.l, v.r))};
+  return o;
+}
+// force cross  vel x* f
+__device__ __forceinline__ s6 cross_force(s6 vel, s6 f) {
+  s6 o = {add3(cross(vel.r, f.r), cross(vel.l, f.l)), cross(vel.r, f.l)};
+  return o;
+}
+// cinert(10) * v : i = [Ixx Iyy Izz Ixy Ixz Iyz mdx mdy mdz m]
+__device__ __forceinline__ s6 inert_mul(const float* i, s6 v) {
+  s6 o;
+  o.r.x = i[0] * v.r.x + i[3] * v.r.y + i[4] * v.r.z - i[8] * v.l.y + i[7] * v.l.z;
+  o.r.y = i[3] * v.r.x + i[1] * v.r.y + i[5] * v.r.z + i[8] * v.l.x - i[6] * v.l.z;
+  o.r.z = i[4] * v.r.x + i[5] * v.r.y + i[2] * v.r.z - i[7] * v.l.x + i[6] * v.l.y;
+  o.l.x = i[8] * v.r.y - i[7] * v.r.z + i[9] * v.l.x;
+  o.l.y = i[6] * v.r.z - i[8] * v.r.x + i[9] * v.l.y;
+  o.l.z = i[7] * v.r.x - i[6] * v.r.y + i[9] * v.l.z;
+  return o;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wave-uniform
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+// LDS ordering between lanes of the one wave that forms the workgroup
+#define WSYNC() __syncthreads()
+
+__device__ __forceinline__ void lds_put6(float* p, s6 v) {
+  *(float4*)p = make_float4(v.r.x, v.r.y, v.r.z, v.l.x);
+  *(float2*)(p + 4) = make_float2(v.l.y, v.l.z);
+}
+__device__ __forceinline__ s6 lds_get6(const float* p) {
+  float4 a = *(const float4*)p; float2 b = *(const float2*)(p + 4);
+  s6 v = {mk3(a.x, a.y, a.z), mk3(a.w, b.x, b.y)};
+  return v;
+}
+
+// farms_core transform helpers on x,y,z,w quaternions (reference drag.pyx:9 cimports)
+struct fq { float x, y, z, w; };
+__device__ __forceinline__ fq fq_conj(fq q) { fq r = {-q.x, -q.y, -q.z, q.w}; return r; }
+__device__ __forceinline__ fq fq_mult(fq a, fq b) {
+  fq o;
+  o.x = a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y;
+  o.y = a.w * b.y - a.x * b.z + a.y * b.w + a.z * b.x;
+  o.z = a.w * b.z + a.x * b.y - a.y * b.x + a.z * b.w;
+  o.w = a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z;
+  return o;
+}
+__device__ __forceinline__ v3 fq_rot(v3 v, fq q) {   // q * (v,0) * conj(q)
+  fq v4 = {v.x, v.y, v.z, 0.f};
+  fq t = fq_mult(fq_mult(q, v4), fq_conj(q));
+  return mk3(t.x, t.y, t.z);
+}
+
+// drag_forces for one link (reference drag.pyx:152-268). Row values are already unit-scaled.
+// Returns false when the link is above the surface (no write, drag.pyx:192-194).
+__device__ __forceinline__ bool drag_link(v3 com_pos, fq urdf2global, fq com2global, v3 lin_w, v3 ang_w,
+                                          float4 c0, float4 c1, float density, const StepArgs& A,
+                                          v3* force_out, v3* torque_out) {
+  if (com_pos.z > A.surface) return false;
+  fq global2urdf = fq_conj(urdf2global);                      // drag.pyx:45
+  fq com2urdf = fq_mult(global2urdf, com2global);             // :46
+  fq urdf2com = fq_conj(com2urdf);                            // :47
+  v3 lin = fq_rot(lin_w, global2urdf);                        // :50-56
+  v3 ang = fq_rot(ang_w, global2urdf);                        // :57-63
+  v3 buoy = mk3(0.f, 0.f, 0.f);
+  float mass = c0.w, height = c1.w;
+  if (A.use_buoyancy && mass > 0.f && com_pos.z < A.surface) {   // :139-146
+    float fz = -1000.f * mass * A.wgravity / density * fminf(fmaxf(A.surface - com_pos.z, 0.f) / height, 1.f);
+    buoy = fq_rot(mk3(0.f, 0.f, fz), global2urdf);
+  }
+  v3 fluid = fq_rot(mk3(A.wvx, A.wvy, A.wvz), global2urdf);   // :235-244
+  lin = sub3(lin, fluid);
+  v3 f, t;
+  f.x = lin.x * lin.x; if (lin.x < 0.f) f.x = -f.x; f.x = f.x * (A.viscosity * c0.x) + buoy.x;   // :83-88
+  f.y = lin.y * lin.y; if (lin.y < 0.f) f.y = -f.y; f.y = f.y * (A.viscosity * c0.y) + buoy.y;
+  f.z = lin.z * lin.z; if (lin.z < 0.f) f.z = -f.z; f.z = f.z * (A.viscosity * c0.z) + buoy.z;
+  t.x = ang.x * ang.x; if (ang.x < 0.f) t.x = -t.x; t.x *= c1.x;                                   // :104-108
+  t.y = ang.y * ang.y; if (ang.y < 0.f) t.y = -t.y; t.y *= c1.y;
+  t.z = ang.z * ang.z; if (ang.z < 0.f) t.z = -t.z; t.z *= c1.z;
+  *force_out = fq_rot(f, urdf2com);                           // :261-262
+  *torque_out = fq_rot(t, urdf2com);
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------
+// the step kernel
+
+struct Carry {          // mjData derived fields owned by lane=body (state before the last integration)
+  v3 xpos; q4 xquat; v3 xipos; v3 linvel, angvel;
+};
+
+__host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
+
+// LDS layout in floats; shared by host (size) and device (carve)
+struct LdsLayout {
+  int P1, P2, CI, CD, HR, RK, QP, QV, XV, VT, ANC, total;
+};
+__host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride) {
+  LdsLayout L;
+  const int nmax = nb > nv ? nb : nv;
+  int o = 0;
+  L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
+  L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
+  L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
+  L.CD = o; o += nv * 8;              // cdof
+  L.HR = o; o += nv * rs;             // depth-indexed rows of H, then L
+  L.RK = o; o += FMJ_MAXD;            // broadcast pivot row
+  L.QP = o; o += r4(nq);
+  L.QV = o; o += r4(nv);
+  L.XV = o; o += r4(nv);
+  L.VT = o; o += 8;
+  L.ANC = o; o += r4(nb * anc_stride) / 4;
+  L.total = o;
+  return L;
+}
+
+template <bool FUSED>
+__global__ void __launch_bounds__(64) fmj_step_kernel(const DevModel M, const StepArgs A) {
+  extern __shared__ __align__(16) float lds[];
+  const int env = blockIdx.x;
+  const int lane = threadIdx.x;
+  const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu, RS = M.rs;
+  const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride);
+  float* T = lds + LL.P1;  float* F = T;       // aliased: T is dead once the chains are composed
+  float* V = lds + LL.P2;  float* BUF = V;     // aliased: V is dead once cvel/cacc are known
+  float* CI = lds + LL.CI;
+  float* CD = lds + LL.CD;
+  float* HR = lds + LL.HR;
+  float* RK = lds + LL.RK;
+  float* QP = lds + LL.QP;
+  float* QV = lds + LL.QV;
+  float* XV = lds + LL.XV;
+  float* VT = lds + LL.VT;
+  const uint8_t* ANC = (const uint8_t*)(lds + LL.ANC);
+
+  // ---- per-lane constants: lane = body role -----------------------------------------------------
+  const bool isb = lane > 0 && lane < nb;
+  const int bl = isb ? lane : 0;
+  const float4 c_pos_mass = M.b_pos_mass[bl];
+  const float4 c_quat = M.b_quat[bl];
+  const float4 c_ipos = M.b_ipos[bl];
+  const float4 c_iquat = M.b_iquat[bl];
+  const float4 c_inertia = M.b_inertia[bl];
+  const float4 c_axis_q0 = M.j_axis_q0[bl];
+  const float4 c_jpos_k = M.j_pos_k[bl];
+  const int4 c_info = M.b_info[bl];     // parent, jtype, qadr, dadr
+  const int4 c_info2 = M.b_info2[bl];   // depth, subsize, link row, swim slot
+  const int jtype = isb ? c_info.y : -1;
+  const int qadr = c_info.z, dadr = c_info.w;
+  const int bdepth = isb ? c_info2.x : -1;
+  const int bsub = isb ? c_info2.y : 0;
+  // lane = dof role
+  const bool isd = lane < nv;
+  const int dl = isd ? lane : 0;
+  const int4 d_info = M.d_info[dl];     // body, depth, subsize(dofs), joint row
+  const float4 d_prm = M.d_prm[dl];     // armature, damping, qposadr bits, hinge/slide flag
+  const int4 d_act = M.d_act[dl];       // first actuator, count, joint sensor slot
+  const int d_qadr = __float_as_int(d_prm.z);
+  const bool d_scalar = isd && d_prm.w != 0.f;   // hinge / slide dof (not part of a free joint)
+  const int ddepth = isd ? d_info.y : 0;
+  const int dsub = isd ? d_info.z : 0;
+
+  // ---- load chains + state ------------------------------------------------------------------------
+  {
+    uint32_t* anc_w = (uint32_t*)(lds + LL.ANC);
+    const int nw = r4(nb * M.anc_stride) / 4;
+    for (int i = lane; i < nw; i += 64) anc_w[i] = ((const uint32_t*)M.b_anc)[i];
+    for (int i = lane; i < nv * RS; i += 64) HR[i] = 0.f;     // padding slots must stay finite (see L)
+  }
+  const float* gq = A.qpos + (size_t)env * nq;
+  const float* gv = A.qvel + (size_t)env * nv;
+  for (int i = lane; i < nq; i += 64) QP[i] = gq[i];
+  for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
+  if (lane < 8) VT[lane] = 0.f;
+  Carry cy;
+  {
+    const float* p = A.xpos + ((size_t)env * nb + bl) * 3; cy.xpos = mk3(p[0], p[1], p[2]);
+    const float* q = A.xquat + ((size_t)env * nb + bl) * 4; cy.xquat.w = q[0]; cy.xquat.x = q[1]; cy.xquat.y = q[2]; cy.xquat.z = q[3];
+    const float* ip = A.xipos + ((size_t)env * nb + bl) * 3; cy.xipos = mk3(ip[0], ip[1], ip[2]);
+    const float* sd = A.sensordata + (size_t)env * M.nsensordata + 6 * (isb ? bl - 1 : 0);
+    cy.linvel = mk3(sd[0], sd[1], sd[2]); cy.angvel = mk3(sd[3], sd[4], sd[5]);
+  }
+  float cy_actsum = 0.f;   // carried motor torque (sum of the joint's actuatorfrc, physics.py:510-524)
+  if (FUSED && d_scalar) {
+    const float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
+#pragma unroll
+    for (int a = 0; a < 4; a++) if (a < d_act.y) cy_actsum += sa[M.a_src[d_act.x + a]] * A.inv_torques;
+  }
+  float xfx = 0.f, xfy = 0.f, xfz = 0.f, xtx = 0.f, xty = 0.f, xtz = 0.f;   // world-frame external force on this body
+  if (!(FUSED && A.do_drag) && A.xfrc_applied && isb) {
+    const float* xf = A.xfrc_applied + ((size_t)env * nb + bl) * 6;
+    xfx = xf[0]; xfy = xf[1]; xfz = xf[2]; xtx = xf[3]; xty = xf[4]; xtz = xf[5];
+  }
+  int warn = 0;
+  float my_qacc = 0.f, pre_q = 0.f, pre_qd = 0.f;
+  float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
+  WSYNC();
+
+  for (int step = 0; step < A.n_steps; step++) {
+    const int it = A.iteration0 + step;
+    // ============ before_step (reference task.py:168-186) ============
+    if (FUSED) {
+      const int index = it % A.buffer_size;
+      v3 r_com = scl3(cy.xipos, A.inv_meters), r_urdf = scl3(cy.xpos, A.inv_meters);
+      v3 r_lin = scl3(cy.linvel, A.inv_velocity), r_ang = scl3(cy.angvel, A.inv_angvel);
+      fq r_q = {cy.xquat.x, cy.xquat.y, cy.xquat.z, cy.xquat.w};   // wxyz -> xyzw (physics.py:458)
+      if (A.do_readout && isb && c_info2.z >= 0) {   // physicslinks2data + physicslinksvelsensors2data
+        float* row = A.links + (size_t)index * A.row_stride_links + ((size_t)env * M.n_links + c_info2.z) * FMJ_LINK_SIZE;
+        *(float4*)(row + 0) = make_float4(r_com.x, r_com.y, r_com.z, r_q.x);
+        *(float4*)(row + 4) = make_float4(r_q.y, r_q.z, r_q.w, r_urdf.x);
+        *(float4*)(row + 8) = make_float4(r_urdf.y, r_urdf.z, r_q.x, r_q.y);
+        *(float4*)(row + 12) = make_float4(r_q.z, r_q.w, r_lin.x, r_lin.y);
+        *(float4*)(row + 16) = make_float4(r_lin.z, r_ang.x, r_ang.y, r_ang.z);
+      }
+      if (A.do_readout && d_scalar && d_info.w >= 0) {   // physicsjoints2data + actuators + limit force
+        float* row = A.joints + (size_t)index * A.row_stride_joints + ((size_t)env * M.n_joints + d_info.w) * FMJ_JOINT_SIZE;
+        row[FMJ_JOINT_POSITION] = QP[d_qadr];
+        row[FMJ_JOINT_VELOCITY] = QV[lane] * A.inv_angvel;
+        row[FMJ_JOINT_TORQUE] = cy_actsum;
+        row[FMJ_JOINT_LIMIT_FORCE] = 0.f;
+      }
+      if (A.do_drag) {                                   // SwimmingHandler.step + xfrc glue
+        xfx = xfy = xfz = xtx = xty = xtz = 0.f;
+        if (isb && c_info2.w >= 0) {
+          const float4 s0 = M.s_c0[c_info2.w], s1 = M.s_c1[c_info2.w], s2 = M.s_c2[c_info2.w];
+          v3 fo, to;
+          if (drag_link(r_com, r_q, r_q, r_lin, r_ang, s0, s1, s2.x, A, &fo, &to)) {
+            float* xr = A.xfrc + (size_t)index * A.row_stride_xfrc + ((size_t)env * M.n_xfrc + __float_as_int(s2.z)) * FMJ_XFRC_SIZE;
+            *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
+            *(float2*)(xr + 2) = make_float2(fo.z, to.x);
+            *(float2*)(xr + 4) = make_float2(to.y, to.z);
+            v3 fw = fq_rot(fo, r_q), tw = fq_rot(to, r_q);
+            xfx = fw.x * A.newtons; xfy = fw.y * A.newtons; xfz = fw.z * A.newtons;
+            xtx = tw.x * A.torques; xty = tw.y * A.torques; xtz = tw.z * A.torques;
+          }
+        }
+      }
+    }
+
+    // ============ mj_step ============
+    // ---- K: local transform, chain composition
+    if (lane < nb) {
+      v3 tp = mk3(c_pos_mass.x, c_pos_mass.y, c_pos_mass.z);
+      q4 tq = {c_quat.x, c_quat.y, c_quat.z, c_quat.w};
+      if (jtype == FMJ_JNT_FREE) {
+        tp = mk3(QP[qadr], QP[qadr + 1], QP[qadr + 2]);
+        q4 rq = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
+        tq = qnormalize(rq);
+      } else if (jtype == FMJ_JNT_HINGE) {
+        const float q = QP[qadr] - c_axis_q0.w;
+        v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), jp = mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z);
+        q4 ql = axisangle(ax, q);
+        v3 d = sub3(jp, qrot(ql, jp));
+        tp = add3(tp, qrot(tq, d));
+        tq = qmul(tq, ql);
+      } else if (jtype == FMJ_JNT_SLIDE) {
+        const float q = QP[qadr] - c_axis_q0.w;
+        v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z);
+        tp = add3(tp, qrot(tq, scl3(ax, q)));
+      }
+      *(float4*)(T + lane * 8) = make_float4(tp.x, tp.y, tp.z, 0.f);
+      *(float4*)(T + lane * 8 + 4) = make_float4(tq.w, tq.x, tq.y, tq.z);
+    }
+    WSYNC();
+    v3 xp = mk3(0.f, 0.f, 0.f);
+    q4 xq = {1.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < M.max_bdepth; k++) {
+      if (k <= bdepth) {
+        const int a = ANC[lane * M.anc_stride + k];
+        float4 ap = *(const float4*)(T + a * 8), aq = *(const float4*)(T + a * 8 + 4);
+        xp = add3(xp, qrot(xq, mk3(ap.x, ap.y, ap.z)));
+        q4 aqq = {aq.x, aq.y, aq.z, aq.w};
+        xq = qmul(xq, aqq);
+      }
+    }
+    xq = qnormalize(xq);
+    const m33 R = q2m(xq);
+    const v3 xi = add3(xp, mrot(R, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
+    // ---- C: subtree CoM of the (single) tree, cinert, cdof
+    const float mass = isb ? c_pos_mass.w : 0.f;
+    const v3 com = mk3(wave_sum(mass * xi.x) * M.mtot_inv, wave_sum(mass * xi.y) * M.mtot_inv, wave_sum(mass * xi.z) * M.mtot_inv);
+    float ci[10];
+    {
+      q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
+      const m33 Ri = q2m(qmul(xq, iq));
+      const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
+      v3 d = sub3(xi, com);
+      ci[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2 + mass * (d.y * d.y + d.z * d.z);
+      ci[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2 + mass * (d.x * d.x + d.z * d.z);
+      ci[2] = Ri.a[6] * Ri.a[6] * i0 + Ri.a[7] * Ri.a[7] * i1 + Ri.a[8] * Ri.a[8] * i2 + mass * (d.x * d.x + d.y * d.y);
+      ci[3] = Ri.a[0] * Ri.a[3] * i0 + Ri.a[1] * Ri.a[4] * i1 + Ri.a[2] * Ri.a[5] * i2 - mass * d.x * d.y;
+      ci[4] = Ri.a[0] * Ri.a[6] * i0 + Ri.a[1] * Ri.a[7] * i1 + Ri.a[2] * Ri.a[8] * i2 - mass * d.x * d.z;
+      ci[5] = Ri.a[3] * Ri.a[6] * i0 + Ri.a[4] * Ri.a[7] * i1 + Ri.a[5] * Ri.a[8] * i2 - mass * d.y * d.z;
+      ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
+      if (!isb) {
+#pragma unroll
+        for (int k = 0; k < 10; k++) ci[k] = 0.f;
+      }
+      if (lane < nb) {
+        *(float4*)(CI + lane * 12) = make_float4(ci[0], ci[1], ci[2], ci[3]);
+        *(float4*)(CI + lane * 12 + 4) = make_float4(ci[4], ci[5], ci[6], ci[7]);
+        *(float2*)(CI + lane * 12 + 8) = make_float2(ci[8], ci[9]);
+      }
+    }
+    s6 vJ = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+    if (jtype == FMJ_JNT_HINGE || jtype == FMJ_JNT_SLIDE) {
+      v3 axw = mrot(R, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
+      s6 cd;
+      if (jtype == FMJ_JNT_HINGE) {
+        v3 anchor = add3(xp, mrot(R, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
+        cd.r = axw; cd.l = cross(axw, sub3(com, anchor));
+      } else { cd.r = mk3(0.f, 0.f, 0.f); cd.l = axw; }
+      lds_put6(CD + dadr * 8, cd);
+      vJ = s6scl(cd, QV[dadr]);
+    } else if (jtype == FMJ_JNT_FREE) {
+      v3 off = sub3(com, xp);
+      s6 vt = {mk3(0.f, 0.f, 0.f), mk3(QV[dadr], QV[dadr + 1], QV[dadr + 2])};
+#pragma unroll
+      for (int k = 0; k < 3; k++) {
+        s6 ct = {mk3(0.f, 0.f, 0.f), mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f)};
+        lds_put6(CD + (dadr + k) * 8, ct);
+        v3 col = mk3(R.a[k], R.a[k + 3], R.a[k + 6]);
+        s6 cr = {col, cross(col, off)};
+        lds_put6(CD + (dadr + 3 + k) * 8, cr);
+        vJ = s6add(vJ, s6scl(cr, QV[dadr + 3 + k]));
+      }
+      lds_put6(VT, vt);
+    }
+    if (lane < nb) lds_put6(V + lane * 8, vJ);
+    WSYNC();
+    // ---- V: chain walk for cvel / cacc
+    s6 cv = lds_get6(VT);
+    s6 ca = {mk3(0.f, 0.f, 0.f), mk3(-M.gx, -M.gy, -M.gz)};
+    for (int k = 0; k < M.max_bdepth; k++) {
+      if (k <= bdepth) {
+        const int a = ANC[lane * M.anc_stride + k];
+        s6 va = lds_get6(V + a * 8);
+        ca = s6add(ca, cross_motion(cv, va));
+        cv = s6add(cv, va);
+      }
+    }
+    if (!isb) { cv.r = cv.l = mk3(0.f, 0.f, 0.f); }
+    // ---- F: body force (inertial minus external), about the common point
+    {
+      s6 f = s6add(inert_mul(ci, ca), cross_force(cv, inert_mul(ci, cv)));
+      v3 fw = mk3(xfx, xfy, xfz), tw = mk3(xtx, xty, xtz);
+      f.r = sub3(f.r, add3(tw, cross(sub3(xi, com), fw)));
+      f.l = sub3(f.l, fw);
+      if (!isb) { f.r = f.l = mk3(0.f, 0.f, 0.f); }
+      if (lane < nb) lds_put6(F + lane * 8, f);     // T region: all chain reads completed before the last WSYNC
+    }
+    WSYNC();
+    // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize)
+    {
+      float crb[10]; s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+#pragma unroll
+      for (int k = 0; k < 10; k++) crb[k] = 0.f;
+      for (int k = 0; k < M.max_subsize; k++) {
+        if (k < bsub) {
+          const int d = lane + k;
+          float4 a = *(const float4*)(CI + d * 12), b = *(const float4*)(CI + d * 12 + 4);
+          float2 c = *(const float2*)(CI + d * 12 + 8);
+          crb[0] += a.x; crb[1] += a.y; crb[2] += a.z; crb[3] += a.w;
+          crb[4] += b.x; crb[5] += b.y; crb[6] += b.z; crb[7] += b.w; crb[8] += c.x; crb[9] += c.y;
+          fs = s6add(fs, lds_get6(F + d * 8));
+        }
+      }
+      WSYNC();
+      if (lane < nb) {
+        *(float4*)(CI + lane * 12) = make_float4(crb[0], crb[1], crb[2], crb[3]);
+        *(float4*)(CI + lane * 12 + 4) = make_float4(crb[4], crb[5], crb[6], crb[7]);
+        *(float2*)(CI + lane * 12 + 8) = make_float2(crb[8], crb[9]);
+        lds_put6(F + lane * 8, fs);
+      }
+    }
+    WSYNC();
+    // ---- Q: qfrc_smooth, buf = crb*cdof  (lane = dof)
+    float qfrc = 0.f;
+    if (isd) {
+      const int body = d_info.x;
+      s6 cd = lds_get6(CD + lane * 8);
+      float crb[10];
+      {
+        float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
+        float2 c = *(const float2*)(CI + body * 12 + 8);
+        crb[0] = a.x; crb[1] = a.y; crb[2] = a.z; crb[3] = a.w; crb[4] = b.x; crb[5] = b.y; crb[6] = b.z; crb[7] = b.w; crb[8] = c.x; crb[9] = c.y;
+      }
+      lds_put6(BUF + lane * 8, inert_mul(crb, cd));   // V region: chain reads completed two WSYNCs ago
+      const float qd = QV[lane];
+      qfrc = -d_prm.y * qd - s6dot(cd, lds_get6(F + body * 8));
+      if (d_scalar) {
+        const float qj = QP[d_qadr];
+        if (M.any_stiffness) {
+          const float kst = M.j_pos_k[body].w;
+          if (kst != 0.f) qfrc -= kst * (qj - A.qpos_spring[(size_t)env * nq + d_qadr]);
+        }
+        float asum = 0.f;
+        float cbase = 0.f;
+        if (FUSED && A.controller == 1) {
+          // phase in cycles kept in fp64 so long runs keep the argument exact (task.py:290: time = iteration*timestep)
+          double cyc = (double)A.w_freq * ((double)it * (double)M.h);
+          cyc -= floor(cyc);
+          cbase = 6.283185307179586f * (float)cyc + A.w_env[env];
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++) {                 // mj_fwdActuation, joint transmission
+          if (a < d_act.y) {
+            const int ai = d_act.x + a, src = M.a_src[ai];
+            const float4 p = M.a_prm[ai], lim = M.a_lim[ai];
+            float c;
+            if (FUSED && A.controller == 1) c = A.w_amp[src] * sinf(cbase - A.w_lag[src]);
+            else c = A.ctrl ? A.ctrl[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
+            c = fminf(fmaxf(c, lim.x), lim.y);
+            float f = p.x * c + p.y + p.z * qj + p.w * qd;
+            f = fminf(fmaxf(f, lim.z), lim.w);
+            if (A.disable_actuation) f = 0.f;
+            if (a == 0) af0 = f; else if (a == 1) af1 = f; else if (a == 2) af2 = f; else af3 = f;
+            asum += f;
+          }
+        }
+        qfrc += asum;
+        cy_actsum = asum * A.inv_torques;
+      }
+    }
+    WSYNC();
+    // ---- M: H entries, one per lane per round
+    for (int e = lane; e < M.nMpad; e += 64) {
+      const uint32_t t = M.m_tab[e];
+      if (t >> 24) {
+        const int i = t & 0xff, j = (t >> 8) & 0xff, dep = (t >> 16) & 0xff;
+        HR[i * RS + dep] = s6dot(lds_get6(CD + j * 8), lds_get6(BUF + i * 8)) + M.m_add[e];
+      }
+    }
+    WSYNC();
+    // ---- L: L'DL with register rows, pivot row k broadcast through LDS.
+    // Padding slots (depth index > own depth) are zero and stay zero: 0 - t*0.
+    float r[FMJ_MAXD];
+#pragma unroll
+    for (int d = 0; d < FMJ_MAXD; d += 4) {
+      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (d < RS && isd) t = *(const float4*)(HR + lane * RS + d);
+      r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
+    }
+    float dinv_mine = 0.f;
+    for (int k = nv - 1; k >= 0; k--) {
+      const int depk = __builtin_amdgcn_readlane(ddepth, k);
+      if (lane == k) {
+#pragma unroll
+        for (int d = 0; d < FMJ_MAXD; d += 4) if (d <= depk) *(float4*)(RK + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
+      }
+      WSYNC();
+      const float dk_inv = 1.0f / RK[depk];
+      const bool anc = lane < k && k < lane + dsub;
+      const float t = anc ? RK[ddepth] * dk_inv : 0.f;
+#pragma unroll
+      for (int d = 0; d < FMJ_MAXD; d += 4) {
+        if (d <= depk) {
+          float4 rk = *(const float4*)(RK + d);
+          r[d] = fmaf(-t, rk.x, r[d]); r[d + 1] = fmaf(-t, rk.y, r[d + 1]);
+          r[d + 2] = fmaf(-t, rk.z, r[d + 2]); r[d + 3] = fmaf(-t, rk.w, r[d + 3]);
+        }
+      }
+      if (lane == k) {
+        dinv_mine = dk_inv;
+#pragma unroll
+        for (int d = 0; d < FMJ_MAXD; d += 4) if (d <= depk)
+          *(float4*)(HR + lane * RS + d) = make_float4(r[d] * dk_inv, r[d + 1] * dk_inv, r[d + 2] * dk_inv, r[d + 3] * dk_inv);
+      }
+      WSYNC();
+    }
+    // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts
+    {
+      float x = qfrc;
+      for (int i = nv - 1; i >= 1; i--) {
+        const float xi_ = bcast(x, i);
+        const bool anc = lane < i && i < lane + dsub;
+        const float l = anc ? HR[i * RS + ddepth] : 0.f;
+        x = fmaf(-l, xi_, x);
+      }
+      x *= dinv_mine;
+      for (int j = 0; j < nv - 1; j++) {
+        const float xj = bcast(x, j);
+        const int depj = __builtin_amdgcn_readlane(ddepth, j);
+        const int subj = __builtin_amdgcn_readlane(dsub, j);
+        const bool desc = isd && j < lane && lane < j + subj;
+        const float l = desc ? HR[lane * RS + depj] : 0.f;
+        x = fmaf(-l, xj, x);
+      }
+      my_qacc = x;
+    }
+    // ---- sensors of the pre-integration state (mj_forward), then semi-implicit Euler
+    cy.xpos = xp; cy.xquat = xq; cy.xipos = xi;
+    cy.angvel = cv.r;
+    cy.linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
+    const float hstep = A.integrate ? M.h : 0.f;     // fmj_forward: mj_forward only
+    if (isd) {
+      if (!(fabsf(my_qacc) <= 1e10f)) warn |= FMJ_WARN_BADQACC;
+      XV[lane] = my_qacc;
+      pre_qd = QV[lane];
+      const float nvel = pre_qd + hstep * my_qacc;
+      QV[lane] = nvel;
+      if (d_scalar) { pre_q = QP[d_qadr]; QP[d_qadr] = pre_q + hstep * nvel; }
+      if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
+    }
+    WSYNC();
+    if (jtype == FMJ_JNT_FREE && A.integrate) {     // free joint position update (lane = root body)
+      QP[qadr] += M.h * QV[dadr]; QP[qadr + 1] += M.h * QV[dadr + 1]; QP[qadr + 2] += M.h * QV[dadr + 2];
+      v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
+      float n = sqrtf(dot3(w, w));
+      q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
+      qo = qnormalize(qo);
+      if (n >= 1e-15f) {
+        q4 qr = axisangle(scl3(w, 1.0f / n), M.h * n);
+        qo = qmul(qo, qr);
+      }
+      QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
+      if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
+    }
+    WSYNC();
+  }
+
+  // ---- store state + derived fields --------------------------------------------------------------
+  float* oq = A.qpos + (size_t)env * nq;
+  float* ov = A.qvel + (size_t)env * nv;
+  for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
+  for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
+  if (A.qacc) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
+  if (lane < nb) {
+    float* p = A.xpos + ((size_t)env * nb + lane) * 3; p[0] = cy.xpos.x; p[1] = cy.xpos.y; p[2] = cy.xpos.z;
+    *(float4*)(A.xquat + ((size_t)env * nb + lane) * 4) = make_float4(cy.xquat.w, cy.xquat.x, cy.xquat.y, cy.xquat.z);
+    float* ip = A.xipos + ((size_t)env * nb + lane) * 3; ip[0] = cy.xipos.x; ip[1] = cy.xipos.y; ip[2] = cy.xipos.z;
+  }
+  float* sd = A.sensordata + (size_t)env * M.nsensordata;
+  if (isb) {
+    float* s = sd + 6 * (lane - 1);
+    *(float2*)(s) = make_float2(cy.linvel.x, cy.linvel.y);
+    *(float2*)(s + 2) = make_float2(cy.linvel.z, cy.angvel.x);
+    *(float2*)(s + 4) = make_float2(cy.angvel.y, cy.angvel.z);
+  }
+  if (d_scalar && A.n_steps > 0) {
+    float* s = sd + 6 * (nb - 1) + 3 * d_act.z;            // jointpos, jointvel, jointlimitfrc
+    s[0] = pre_q; s[1] = pre_qd; s[2] = 0.f;
+    float* sa = sd + 6 * (nb - 1) + 3 * M.njs;            // actuatorfrc
+    if (0 < d_act.y) sa[M.a_src[d_act.x + 0]] = af0;
+    if (1 < d_act.y) sa[M.a_src[d_act.x + 1]] = af1;
+    if (2 < d_act.y) sa[M.a_src[d_act.x + 2]] = af2;
+    if (3 < d_act.y) sa[M.a_src[d_act.x + 3]] = af3;
+  }
+  if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * A.n_steps;
+  if (__ballot(warn != 0)) {
+    int w = warn;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
+    if (lane == 0) A.status[env] |= w;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// standalone operators (same arithmetic as the fused loop; one wave per env)
+
+// SwimmingHandler.step (reference drag.pyx:389-411): lane = swimming link
+__global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const StepArgs A) {
+  const int env = blockIdx.x;
+  for (int s = threadIdx.x; s < M.ns; s += 64) {
+    const float4 s0 = M.s_c0[s], s1 = M.s_c1[s], s2 = M.s_c2[s];
+    const int li = __float_as_int(s2.y), xi = __float_as_int(s2.z), body = __float_as_int(s2.w);
+    const float* row = A.links + ((size_t)env * M.n_links + li) * FMJ_LINK_SIZE;
+    const float4 a = *(const float4*)(row), b = *(const float4*)(row + 4), c = *(const float4*)(row + 8),
+                 d = *(const float4*)(row + 12), e = *(const float4*)(row + 16);
+    v3 com = mk3(a.x, a.y, a.z);
+    fq comq = {a.w, b.x, b.y, b.z};
+    fq urdfq = {c.z, c.w, d.x, d.y};
+    v3 lin = mk3(d.z, d.w, e.x), ang = mk3(e.y, e.z, e.w);
+    v3 fo, to;
+    const bool applied = drag_link(com, urdfq, comq, lin, ang, s0, s1, s2.x, A, &fo, &to);
+    if (applied) {
+      float* xr = A.xfrc + ((size_t)env * M.n_xfrc + xi) * FMJ_XFRC_SIZE;
+      *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
+      *(float2*)(xr + 2) = make_float2(fo.z, to.x);
+      *(float2*)(xr + 4) = make_float2(to.y, to.z);
+    }
+    if (A.xfrc_applied_out) {
+      float* xa = A.xfrc_applied_out + ((size_t)env * M.nbody + body) * 6;
+      if (applied) {
+        v3 fw = fq_rot(fo, comq), tw = fq_rot(to, comq);
+        xa[0] = fw.x * A.newtons; xa[1] = fw.y * A.newtons; xa[2] = fw.z * A.newtons;
+        xa[3] = tw.x * A.torques; xa[4] = tw.y * A.torques; xa[5] = tw.z * A.torques;
+      } else { for (int k = 0; k < 6; k++) xa[k] = 0.f; }
+    }
+  }
+}
+
+// physics2data (reference physics.py:527-545): lane = link row, then lane = joint row
+__global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, const StepArgs A, const int links_only,
+                                                               const int* links_body, const int* joints_dof) {
+  const int env = blockIdx.x, nb = M.nbody;
+  const float* sd = A.sensordata + (size_t)env * M.nsensordata;
+  for (int i = threadIdx.x; i < M.n_links; i += 64) {
+    const int b = links_body[i];
+    const float* p = A.xpos + ((size_t)env * nb + b) * 3;
+    const float* q = A.xquat + ((size_t)env * nb + b) * 4;
+    const float* ip = A.xipos + ((size_t)env * nb + b) * 3;
+    const float* s = sd + 6 * (b - 1);
+    float* row = A.links + ((size_t)env * M.n_links + i) * FMJ_LINK_SIZE;
+    const float im = A.inv_meters, iv = A.inv_velocity, ia = A.inv_angvel;
+    *(float4*)(row + 0) = make_float4(ip[0] * im, ip[1] * im, ip[2] * im, q[1]);
+    *(float4*)(row + 4) = make_float4(q[2], q[3], q[0], p[0] * im);
+    *(float4*)(row + 8) = make_float4(p[1] * im, p[2] * im, q[1], q[2]);
+    *(float4*)(row + 12) = make_float4(q[3], q[0], s[0] * iv, s[1] * iv);
+    *(float4*)(row + 16) = make_float4(s[2] * iv, s[3] * ia, s[4] * ia, s[5] * ia);
+  }
+  if (links_only) return;
+  const float* sa = sd + 6 * (nb - 1) + 3 * M.njs;
+  for (int i = threadIdx.x; i < M.n_joints; i += 64) {
+    const int d = joints_dof[i];
+    const float4 prm = M.d_prm[d];
+    const int4 act = M.d_act[d];
+    float* row = A.joints + ((size_t)env * M.n_joints + i) * FMJ_JOINT_SIZE;
+    row[FMJ_JOINT_POSITION] = A.qpos[(size_t)env * M.nq + __float_as_int(prm.z)];
+    row[FMJ_JOINT_VELOCITY] = A.qvel[(size_t)env * M.nv + d] * A.inv_angvel;
+    float t = 0.f;
+    for (int a = 0; a < act.y; a++) t += sa[M.a_src[act.x + a]] * A.inv_torques;
+    row[FMJ_JOINT_TORQUE] = t;
+    row[FMJ_JOINT_LIMIT_FORCE] = sd[6 * (nb - 1) + 3 * act.z + 2] * A.inv_torques;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// host side
+
+template <class T>
+static int upload(fmj_ctx* c, const std::vector<T>& h, const T** dptr) {
+  void* d = nullptr;
+  size_t bytes = (h.size() ? h.size() : 1) * sizeof(T);
+  HIP_TRY(hipMalloc(&d, bytes));
+  c->allocs.push_back(d);
+  if (h.size()) HIP_TRY(hipMemcpy(d, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dptr = (const T*)d;
+  return FMJ_OK;
+}
+#define UP(vec, field) do { int rc_ = upload(c, vec, &c->dm.field); if (rc_) { fmj_destroy(c); return rc_; } } while (0)
+
+static float4 f4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
+static float ibits(int i) { float f; memcpy(&f, &i, 4); return f; }
+
+extern "C" {
+
+const char* fmj_last_error(void) { return g_err.c_str(); }
+int fmj_abi_version(void) { return FMJ_ABI_VERSION; }
+
+void fmj_destroy(fmj_ctx* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  for (void* p : c->allocs) (void)hipFree(p);
+  delete c;
+}
+
+int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out) {
+  if (!m || !out || n_envs <= 0) return set_err(FMJ_ERR_ARG, "fmj_create: NULL model/out or n_envs <= 0");
+  *out = nullptr;
+  if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
+  const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
+  if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
+  if (m->ngeom > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: collision geoms / contacts are not in the HIP path yet");
+  for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: joint limits are not in the HIP path yet");
+  // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
+  if (m->body_parentid[1] != 0) return set_err(FMJ_ERR_ARG, "fmj_create: body 1 must be the root (parent = world)");
+  std::vector<int> bdepth(nb, 0), subsize(nb, 1);
+  for (int i = 2; i < nb; i++) {
+    int p = m->body_parentid[i];
+    if (p < 1 || p >= i) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: single kinematic tree with parent-first numbering required");
+    bool ok = false;                      // DFS pre-order: parent(i) is an ancestor-or-self of i-1
+    for (int a = i - 1; a >= 1; a = m->body_parentid[a]) if (a == p) { ok = true; break; }
+    if (!ok) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: bodies must be numbered in depth-first pre-order");
+    bdepth[i] = bdepth[p] + 1;
+  }
+  for (int i = nb - 1; i >= 2; i--) subsize[m->body_parentid[i]] += subsize[i];
+  int max_bdepth = 0, max_sub = 0;
+  for (int i = 1; i < nb; i++) { if (bdepth[i] + 1 > max_bdepth) max_bdepth = bdepth[i] + 1; if (subsize[i] > max_sub) max_sub = subsize[i]; }
+  if (max_bdepth > 255) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: body chain too long");
+  int expect_dof = 0, expect_q = 0;
+  for (int i = 1; i < nb; i++) {
+    int j = m->body_jntadr[i];
+    if (j < 0) { if (m->body_dofnum[i] != 0) return set_err(FMJ_ERR_ARG, "fmj_create: body_dofnum without joint"); continue; }
+    if (m->jnt_bodyid[j] != i) return set_err(FMJ_ERR_ARG, "fmj_create: jnt_bodyid inconsistent");
+    int t = m->jnt_type[j];
+    int nd = t == FMJ_JNT_FREE ? 6 : 1, nqj = t == FMJ_JNT_FREE ? 7 : 1;
+    if (t == FMJ_JNT_BALL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: ball joints unsupported (reference mjcf.py emits hinge/slide/free only)");
+    if (t == FMJ_JNT_FREE && i != 1) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: free joint only on the root body");
+    if (m->body_dofnum[i] != nd || m->body_dofadr[i] != expect_dof || m->jnt_dofadr[j] != expect_dof || m->jnt_qposadr[j] != expect_q)
+      return set_err(FMJ_ERR_ARG, "fmj_create: dof/qpos addresses must follow body order with one joint per body");
+    expect_dof += nd; expect_q += nqj;
+  }
+  if (expect_dof != nv || expect_q != nq) return set_err(FMJ_ERR_ARG, "fmj_create: nv/nq do not match the joints");
+  std::vector<int> ddepth(nv, 0), dsub(nv, 1);
+  int max_ddepth = 0;
+  for (int d = 0; d < nv; d++) {
+    int p = m->dof_parentid[d];
+    if (p >= d) return set_err(FMJ_ERR_ARG, "fmj_create: dof_parentid must precede the dof");
+    ddepth[d] = p < 0 ? 0 : ddepth[p] + 1;
+    if (ddepth[d] > max_ddepth) max_ddepth = ddepth[d];
+  }
+  for (int d = nv - 1; d >= 0; d--) if (m->dof_parentid[d] >= 0) dsub[m->dof_parentid[d]] += dsub[d];
+  if (max_ddepth + 1 > FMJ_MAXD) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: dof chain longer than 32");
+  std::vector<int> nact(nj, 0);
+  for (int a = 0; a < nu; a++) {
+    int j = m->actuator_jntid[a];
+    if (j < 0 || j >= nj || m->jnt_type[j] == FMJ_JNT_FREE) return set_err(FMJ_ERR_ARG, "fmj_create: actuator must act on a hinge/slide joint");
+    if (++nact[j] > 4) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 4 actuators on one joint");
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(FMJ_ERR_NODEVICE, "fmj_create: no HIP device visible");
+  if (device < 0 || device >= ndev) return set_err(FMJ_ERR_ARG, "fmj_create: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+
+  fmj_ctx* c = new fmj_ctx();
+  c->device = device; c->n_envs = n_envs; c->nbody = nb; c->nv = nv; c->nu = nu; c->njnt = nj;
+  c->d_b_info2 = nullptr; c->d_d_info = nullptr;
+  DevModel& D = c->dm;
+  memset(&D, 0, sizeof D);
+  D.nbody = nb; D.nv = nv; D.nq = nq; D.nu = nu; D.njnt = nj; D.nM = m->nM;
+  D.max_bdepth = max_bdepth; D.max_subsize = max_sub;
+  D.rs = r4(max_ddepth + 1);
+  D.root_free = m->body_jntadr[1] >= 0 && m->jnt_type[m->body_jntadr[1]] == FMJ_JNT_FREE;
+  D.h = (float)m->timestep; D.gx = (float)m->gravity[0]; D.gy = (float)m->gravity[1]; D.gz = (float)m->gravity[2];
+  double mtot = 0; for (int i = 1; i < nb; i++) mtot += m->body_mass[i];
+  D.mtot_inv = (float)(1.0 / mtot);
+  D.anc_stride = r4(max_bdepth);
+  int njs = 0; for (int j = 0; j < nj; j++) njs += m->jnt_type[j] != FMJ_JNT_FREE;
+  D.njs = njs; D.nsensordata = 6 * (nb - 1) + 3 * njs + nu;
+  c->layout.nsensordata = D.nsensordata; c->layout.framelinvel_adr = 0; c->layout.jointpos_adr = 6 * (nb - 1);
+  c->layout.actuatorfrc_adr = 6 * (nb - 1) + 3 * njs; c->layout.first_link_body = 1;
+  c->layout.first_sensor_jnt = D.root_free ? 1 : 0;
+
+  std::vector<float4> b_pos_mass(64), b_quat(64), b_ipos(64), b_iquat(64), b_inertia(64), j_axis_q0(64), j_pos_k(64);
+  std::vector<int4> b_info(64), b_info2(64), d_info(64), d_act(64);
+  std::vector<float4> d_prm(64);
+  std::vector<uint8_t> b_anc((size_t)r4(nb * D.anc_stride), 0);
+  c->body_link_row.assign(nb, -1); c->dof_joint_row.assign(nv, -1); c->body_swim.assign(nb, -1);
+  c->jnt_dofadr.assign(m->jnt_dofadr, m->jnt_dofadr + nj); c->jnt_type.assign(m->jnt_type, m->jnt_type + nj);
+  int any_k = 0;
+  for (int i = 0; i < 64; i++) {
+    b_pos_mass[i] = f4(0, 0, 0, 0); b_quat[i] = f4(1, 0, 0, 0); b_ipos[i] = f4(0, 0, 0, 0); b_iquat[i] = f4(1, 0, 0, 0);
+    b_inertia[i] = f4(0, 0, 0, 0); j_axis_q0[i] = f4(0, 0, 1, 0); j_pos_k[i] = f4(0, 0, 0, 0);
+    b_info[i] = make_int4(0, -1, 0, 0); b_info2[i] = make_int4(-1, 0, -1, -1);
+    d_info[i] = make_int4(0, 0, 0, -1); d_prm[i] = f4(0, 0, 0, 0); d_act[i] = make_int4(0, 0, 0, 0);
+  }
+  for (int i = 1; i < nb; i++) {
+    b_pos_mass[i] = f4(m->body_pos[3 * i], m->body_pos[3 * i + 1], m->body_pos[3 * i + 2], m->body_mass[i]);
+    b_quat[i] = f4(m->body_quat[4 * i], m->body_quat[4 * i + 1], m->body_quat[4 * i + 2], m->body_quat[4 * i + 3]);
+    b_ipos[i] = f4(m->body_ipos[3 * i], m->body_ipos[3 * i + 1], m->body_ipos[3 * i + 2], 0);
+    b_iquat[i] = f4(m->body_iquat[4 * i], m->body_iquat[4 * i + 1], m->body_iquat[4 * i + 2], m->body_iquat[4 * i + 3]);
+    b_inertia[i] = f4(m->body_inertia[3 * i], m->body_inertia[3 * i + 1], m->body_inertia[3 * i + 2], 0);
+    int j = m->body_jntadr[i];
+    if (j >= 0) {
+      double q0 = m->jnt_type[j] == FMJ_JNT_FREE ? 0.0 : m->qpos0[m->jnt_qposadr[j]];
+      j_axis_q0[i] = f4(m->jnt_axis[3 * j], m->jnt_axis[3 * j + 1], m->jnt_axis[3 * j + 2], q0);
+      j_pos_k[i] = f4(m->jnt_pos[3 * j], m->jnt_pos[3 * j + 1], m->jnt_pos[3 * j + 2], m->jnt_stiffness[j]);
+      if (m->jnt_type[j] != FMJ_JNT_FREE && m->jnt_stiffness[j] != 0) any_k = 1;
+      b_info[i] = make_int4(m->body_parentid[i], m->jnt_type[j], m->jnt_qposadr[j], m->jnt_dofadr[j]);
+    } else b_info[i] = make_int4(m->body_parentid[i], -1, 0, 0);
+    c->body_link_row[i] = i - 1;
+    b_info2[i] = make_int4(bdepth[i], subsize[i], i - 1, -1);
+    int k = bdepth[i];
+    for (int a = i; a >= 1; a = m->body_parentid[a]) b_anc[(size_t)i * D.anc_stride + k--] = (uint8_t)a;
+  }
+  D.any_stiffness = any_k;
+  D.n_links = nb - 1; D.n_joints = njs; D.n_xfrc = nb - 1; D.ns = 0;
+  // actuators sorted by dof
+  std::vector<float4> a_prm, a_lim; std::vector<int> a_src;
+  int sj = 0;
+  for (int j = 0; j < nj; j++) {
+    int d0 = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == FMJ_JNT_FREE) {
+      for (int k = 0; k < 6; k++) { d_info[d0 + k] = make_int4(m->jnt_bodyid[j], ddepth[d0 + k], dsub[d0 + k], -1);
+        d_prm[d0 + k] = f4(m->dof_armature[d0 + k], m->dof_damping[d0 + k], 0, 0); d_act[d0 + k] = make_int4(0, 0, 0, 0); }
+      continue;
+    }
+    d_info[d0] = make_int4(m->jnt_bodyid[j], ddepth[d0], dsub[d0], sj);
+    c->dof_joint_row[d0] = sj;
+    d_prm[d0] = make_float4((float)m->dof_armature[d0], (float)m->dof_damping[d0], ibits(m->jnt_qposadr[j]), 1.0f);
+    int first = (int)a_src.size(), cnt = 0;
+    for (int a = 0; a < nu; a++) if (m->actuator_jntid[a] == j) {
+      a_prm.push_back(f4(m->actuator_gain[a], m->actuator_bias[3 * a], m->actuator_bias[3 * a + 1], m->actuator_bias[3 * a + 2]));
+      double cl = m->actuator_ctrllimited[a] ? m->actuator_ctrlrange[2 * a] : -3.0e38, ch = m->actuator_ctrllimited[a] ? m->actuator_ctrlrange[2 * a + 1] : 3.0e38;
+      double fl = m->actuator_forcelimited[a] ? m->actuator_forcerange[2 * a] : -3.0e38, fh = m->actuator_forcelimited[a] ? m->actuator_forcerange[2 * a + 1] : 3.0e38;
+      a_lim.push_back(f4(cl, ch, fl, fh)); a_src.push_back(a); cnt++;
+    }
+    d_act[d0] = make_int4(first, cnt, sj, 0);
+    sj++;
+  }
+  // M entry table
+  int nMpad = ((m->nM + 63) / 64) * 64;
+  std::vector<uint32_t> m_tab(nMpad, 0); std::vector<float> m_add(nMpad, 0.f);
+  int e = 0;
+  for (int i = 0; i < nv; i++) {
+    if (m->dof_Madr[i] != e) { fmj_destroy(c); return set_err(FMJ_ERR_ARG, "fmj_create: dof_Madr inconsistent"); }
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
+      m_tab[e] = (uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)ddepth[j] << 16) | (1u << 24);
+      if (i == j) m_add[e] = (float)(m->dof_armature[i] + m->timestep * m->dof_damping[i]);
+      e++;
+    }
+  }
+  if (e != m->nM) { fmj_destroy(c); return set_err(FMJ_ERR_ARG, "fmj_create: nM inconsistent"); }
+  D.nMpad = nMpad;
+  c->h_b_info2.assign((int*)b_info2.data(), (int*)b_info2.data() + 64 * 4);
+  c->h_d_info.assign((int*)d_info.data(), (int*)d_info.data() + 64 * 4);
+
+  UP(b_pos_mass, b_pos_mass); UP(b_quat, b_quat); UP(b_ipos, b_ipos); UP(b_iquat, b_iquat); UP(b_inertia, b_inertia);
+  UP(j_axis_q0, j_axis_q0); UP(j_pos_k, j_pos_k); UP(b_info, b_info); UP(b_info2, b_info2); UP(b_anc, b_anc);
+  UP(d_info, d_info); UP(d_prm, d_prm); UP(d_act, d_act); UP(a_prm, a_prm); UP(a_lim, a_lim); UP(a_src, a_src);
+  UP(m_tab, m_tab); UP(m_add, m_add);
+  c->d_b_info2 = (int4*)D.b_info2; c->d_d_info = (int4*)D.d_info;
+  std::vector<float4> empty4(1, f4(0, 0, 0, 0));
+  UP(empty4, s_c0); UP(empty4, s_c1); UP(empty4, s_c2);
+  LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride);
+  c->lds_bytes = (size_t)L.total * sizeof(float);
+  if (c->lds_bytes > 64 * 1024) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)fmj_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)fmj_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    if (e1 != hipSuccess || e2 != hipSuccess) { fmj_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_create: LDS request too large"); }
+  }
+  *out = c;
+  return FMJ_OK;
+}
+
+int fmj_get_sensor_layout(const fmj_ctx* c, fmj_sensor_layout_t* out) {
+  if (!c || !out) return set_err(FMJ_ERR_ARG, "fmj_get_sensor_layout: NULL");
+  *out = c->layout; return FMJ_OK;
+}
+
+int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threads_per_env) {
+  if (!c) return set_err(FMJ_ERR_ARG, "fmj_kernel_info: NULL ctx");
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)c->lds_bytes;
+  if (threads_per_env) *threads_per_env = 64;
+  return FMJ_OK;
+}
+
+int fmj_set_swimming(fmj_ctx* c, int32_t ns, const int32_t* links_index, const int32_t* xfrc_index,
+                     const int32_t* body_index, const double* coefficients, const double* masses,
+                     const double* heights, const double* densities) {
+  if (!c || ns < 0 || (ns > 0 && (!links_index || !xfrc_index || !body_index || !coefficients || !masses || !heights || !densities)))
+    return set_err(FMJ_ERR_ARG, "fmj_set_swimming: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  std::vector<float4> c0(ns ? ns : 1), c1(ns ? ns : 1), c2(ns ? ns : 1);
+  for (int b = 0; b < 64; b++) c->h_b_info2[4 * b + 3] = -1;
+  int max_x = 0;
+  for (int s = 0; s < ns; s++) {
+    int b = body_index[s];
+    if (b < 1 || b >= c->nbody) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: body index out of range");
+    if (links_index[s] < 0 || links_index[s] >= c->dm.n_links || xfrc_index[s] < 0) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: row index out of range");
+    if (c->h_b_info2[4 * b + 2] != links_index[s]) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: links_index must be the readout row of the same body (call fmj_set_readout_maps first)");
+    const double* k = coefficients + 6 * s;
+    c0[s] = f4(k[0], k[1], k[2], masses[s]); c1[s] = f4(k[3], k[4], k[5], heights[s]);
+    c2[s] = make_float4((float)densities[s], ibits(links_index[s]), ibits(xfrc_index[s]), ibits(b));
+    c->h_b_info2[4 * b + 3] = s;
+    if (xfrc_index[s] + 1 > max_x) max_x = xfrc_index[s] + 1;
+  }
+  int rc;
+  if ((rc = upload(c, c0, &c->dm.s_c0)) || (rc = upload(c, c1, &c->dm.s_c1)) || (rc = upload(c, c2, &c->dm.s_c2))) return rc;
+  HIP_TRY(hipMemcpy(c->d_b_info2, c->h_b_info2.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
+  c->dm.ns = ns;
+  if (max_x > c->dm.n_xfrc) c->dm.n_xfrc = max_x;
+  return FMJ_OK;
+}
+
+int fmj_set_readout_maps(fmj_ctx* c, int32_t n_links, const int32_t* links_body, int32_t n_joints, const int32_t* joints_jnt) {
+  if (!c || n_links < 0 || n_joints < 0 || (n_links && !links_body) || (n_joints && !joints_jnt)) return set_err(FMJ_ERR_ARG, "fmj_set_readout_maps: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  for (int b = 0; b < 64; b++) c->h_b_info2[4 * b + 2] = -1;
+  for (int d = 0; d < 64; d++) c->h_d_info[4 * d + 3] = -1;
+  for (int i = 0; i < n_links; i++) {
+    int b = links_body[i];
+    if (b < 1 || b >= c->nbody) return set_err(FMJ_ERR_ARG, "fmj_set_readout_maps: link body out of range");
+    c->h_b_info2[4 * b + 2] = i;
+  }
+  for (int i = 0; i < n_joints; i++) {
+    int j = joints_jnt[i];
+    if (j < 0 || j >= c->njnt || c->jnt_type[j] == FMJ_JNT_FREE) return set_err(FMJ_ERR_ARG, "fmj_set_readout_maps: joint rows must be hinge/slide joints");
+    c->h_d_info[4 * c->jnt_dofadr[j] + 3] = i;
+  }
+  HIP_TRY(hipMemcpy(c->d_b_info2, c->h_b_info2.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_d_info, c->h_d_info.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
+  c->dm.n_links = n_links; c->dm.n_joints = n_joints;
+  if (c->dm.n_xfrc < n_links) c->dm.n_xfrc = n_links;
+  return FMJ_OK;
+}
+
+static int fill_data(const fmj_ctx* c, const fmj_data* d, StepArgs* A, bool need_state) {
+  memset(A, 0, sizeof *A);
+  if (!d) return set_err(FMJ_ERR_ARG, "NULL fmj_data");
+  if (need_state && (!d->qpos || !d->qvel || !d->xpos || !d->xquat || !d->xipos || !d->sensordata || !d->status))
+    return set_err(FMJ_ERR_ARG, "fmj_data: qpos, qvel, xpos, xquat, xipos, sensordata, status are required");
+  A->qpos = d->qpos; A->qvel = d->qvel; A->ctrl = d->ctrl; A->qpos_spring = d->qpos_spring; A->xfrc_applied = d->xfrc_applied;
+  A->xpos = d->xpos; A->xquat = d->xquat; A->xipos = d->xipos; A->sensordata = d->sensordata; A->qacc = d->qacc;
+  A->time = d->time; A->status = d->status; A->n_envs = c->n_envs;
+  A->inv_meters = A->inv_velocity = A->inv_angvel = A->inv_torques = A->newtons = A->torques = 1.0f;
+  A->buffer_size = 1;
+  return FMJ_OK;
+}
+
+static void fill_units(StepArgs* A, const fmj_units* u) {
+  A->inv_meters = 1.0f / u->meters; A->inv_velocity = 1.0f / u->velocity; A->inv_angvel = 1.0f / u->angular_velocity;
+  A->inv_torques = 1.0f / u->torques; A->newtons = u->newtons; A->torques = u->torques;
+}
+static void fill_water(StepArgs* A, const fmj_water* w) {
+  A->surface = w->surface; A->viscosity = w->viscosity; A->wvx = w->velocity[0]; A->wvy = w->velocity[1]; A->wvz = w->velocity[2];
+  A->wgravity = w->gravity; A->use_buoyancy = w->use_buoyancy;
+}
+
+int fmj_step(fmj_ctx* c, const fmj_data* d, int32_t n_steps, int64_t ctrl_step_stride, void* stream) {
+  if (!c) return set_err(FMJ_ERR_ARG, "fmj_step: NULL ctx");
+  if (n_steps < 0) return set_err(FMJ_ERR_ARG, "fmj_step: n_steps < 0");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step: qpos_spring required (model has joint stiffness)");
+  A.n_steps = n_steps; A.ctrl_step_stride = ctrl_step_stride; A.integrate = 1;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_step_kernel<false>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_forward(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, void* stream) {
+  if (!c) return set_err(FMJ_ERR_ARG, "fmj_forward: NULL ctx");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_forward: qpos_spring required (model has joint stiffness)");
+  A.n_steps = 1; A.integrate = 0; A.disable_actuation = disable_actuation;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_step_kernel<false>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void* stream) {
+  if (!c || !a) return set_err(FMJ_ERR_ARG, "fmj_step_fused: NULL argument");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  if (a->n_steps < 0 || a->buffer_size < 1) return set_err(FMJ_ERR_ARG, "fmj_step_fused: bad n_steps/buffer_size");
+  if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step_fused: qpos_spring required");
+  if (a->do_readout && (!a->rows_base.links || !a->rows_base.joints)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: readout needs links and joints rows");
+  if (a->do_drag && (!a->rows_base.xfrc || c->dm.ns == 0)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: drag needs xfrc rows and fmj_set_swimming");
+  if (a->controller == 1 && (!a->wave.amplitude || !a->wave.phase_lag || !a->wave.env_phase)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: wave controller arrays missing");
+  if (a->controller != 0 && a->controller != 1) return set_err(FMJ_ERR_ARG, "fmj_step_fused: unknown controller");
+  A.integrate = 1;
+  A.n_steps = a->n_steps; A.iteration0 = a->iteration0; A.buffer_size = a->buffer_size; A.do_readout = a->do_readout;
+  A.do_drag = a->do_drag; A.controller = a->controller; A.ctrl_step_stride = a->ctrl_step_stride;
+  A.row_stride_links = a->row_stride_links; A.row_stride_joints = a->row_stride_joints; A.row_stride_xfrc = a->row_stride_xfrc;
+  A.links = a->rows_base.links; A.joints = a->rows_base.joints; A.xfrc = a->rows_base.xfrc;
+  fill_units(&A, &a->units); fill_water(&A, &a->water);
+  A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_step_kernel<true>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_drag(fmj_ctx* c, const fmj_rows* rows, const fmj_water* water, const fmj_units* units, float* xfrc_applied, void* stream) {
+  if (!c || !rows || !water || !units || !rows->links || !rows->xfrc) return set_err(FMJ_ERR_ARG, "fmj_drag: NULL argument");
+  if (c->dm.ns == 0) return set_err(FMJ_ERR_ARG, "fmj_drag: call fmj_set_swimming first");
+  StepArgs A; memset(&A, 0, sizeof A);
+  A.n_envs = c->n_envs; A.links = rows->links; A.xfrc = rows->xfrc; A.xfrc_applied_out = xfrc_applied;
+  fill_units(&A, units); fill_water(&A, water);
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_drag_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_physics2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const fmj_units* units, int32_t links_only, void* stream) {
+  if (!c || !d || !rows || !units || !rows->links || (!links_only && !rows->joints)) return set_err(FMJ_ERR_ARG, "fmj_physics2data: NULL argument");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  A.links = rows->links; A.joints = rows->joints; fill_units(&A, units);
+  HIP_TRY(hipSetDevice(c->device));
+  // device copies of the row -> body / dof maps (rebuilt from the host mirrors; tiny)
+  std::vector<int> lb(c->dm.n_links ? c->dm.n_links : 1, 1), jd(c->dm.n_joints ? c->dm.n_joints : 1, 0);
+  for (int b = 1; b < c->nbody; b++) if (c->h_b_info2[4 * b + 2] >= 0) lb[c->h_b_info2[4 * b + 2]] = b;
+  for (int dd = 0; dd < c->nv; dd++) if (c->h_d_info[4 * dd + 3] >= 0) jd[c->h_d_info[4 * dd + 3]] = dd;
+  static thread_local int* d_lb = nullptr; static thread_local int* d_jd = nullptr; static thread_local size_t cap = 0;
+  size_t need = lb.size() + jd.size();
+  if (need > cap) { if (d_lb) (void)hipFree(d_lb); HIP_TRY(hipMalloc((void**)&d_lb, need * sizeof(int))); cap = need; }
+  d_jd = d_lb + lb.size();
+  HIP_TRY(hipMemcpyAsync(d_lb, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+  HIP_TRY(hipMemcpyAsync(d_jd, jd.data(), jd.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
+  hipLaunchKernelGGL(fmj_physics2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)links_only, (const int*)d_lb, (const int*)d_jd);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_sc(const char* name) {
+  static const struct { const char* n; int v; } tab[] = {
+      {"LINK_COM_POS", FMJ_LINK_COM_POS}, {"LINK_COM_QUAT", FMJ_LINK_COM_QUAT}, {"LINK_URDF_POS", FMJ_LINK_URDF_POS},
+      {"LINK_URDF_QUAT", FMJ_LINK_URDF_QUAT}, {"LINK_COM_LINVEL", FMJ_LINK_COM_LINVEL}, {"LINK_COM_ANGVEL", FMJ_LINK_COM_ANGVEL},
+      {"LINK_SIZE", FMJ_LINK_SIZE}, {"JOINT_POSITION", FMJ_JOINT_POSITION}, {"JOINT_VELOCITY", FMJ_JOINT_VELOCITY},
+      {"JOINT_FORCE", FMJ_JOINT_FORCE}, {"JOINT_TORQUE3", FMJ_JOINT_TORQUE3}, {"JOINT_TORQUE", FMJ_JOINT_TORQUE},
+      {"JOINT_LIMIT_FORCE", FMJ_JOINT_LIMIT_FORCE}, {"JOINT_SIZE", FMJ_JOINT_SIZE}, {"CONTACT_REACTION", FMJ_CONTACT_REACTION},
+      {"CONTACT_FRICTION", FMJ_CONTACT_FRICTION}, {"CONTACT_TOTAL", FMJ_CONTACT_TOTAL}, {"CONTACT_POSITION", FMJ_CONTACT_POSITION},
+      {"CONTACT_SIZE", FMJ_CONTACT_SIZE}, {"XFRC_FORCE", FMJ_XFRC_FORCE}, {"XFRC_TORQUE", FMJ_XFRC_TORQUE}, {"XFRC_SIZE", FMJ_XFRC_SIZE}};
+  if (!name) return -1;
+  for (auto& t : tab) if (!strcmp(t.n, name)) return t.v;
+  return -1;
+}
+
+}  // extern "C"

@@ -259,10 +259,25 @@ class Model:
     def _from_builder(cls, b: ModelBuilder) -> 'Model':
         m = cls()
         m.name = b.name
-        bodies = b.bodies
-        nb = len(bodies)
-        for i, body in enumerate(bodies):
+        nb = len(b.bodies)
+        for i, body in enumerate(b.bodies):
             assert body.parent < i, 'bodies must be added parent-first'
+        # MuJoCo numbers bodies in depth-first pre-order of the XML nesting (children in the order
+        # they were added); a subtree is then a contiguous id range, which the kernels rely on.
+        children = [[] for _ in range(nb)]
+        for i in range(1, nb):
+            children[b.bodies[i].parent].append(i)
+        order, stack = [], [0]
+        while stack:
+            i = stack.pop()
+            order.append(i)
+            stack.extend(reversed(children[i]))
+        new_of_old = {old: new for new, old in enumerate(order)}
+        bodies = []
+        for old in order:
+            body = b.bodies[old]
+            bodies.append(_Body(body.name, new_of_old.get(body.parent, -1), body.pos, body.quat, body.mass,
+                                body.ipos, body.iquat, body.inertia, body.joint, body.swimming, body.geoms))
         m.timestep = b.timestep
         m.gravity = b.gravity.copy()
         m.nbody = nb

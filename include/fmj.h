@@ -232,6 +232,11 @@ int fmj_set_readout_maps(fmj_ctx* ctx, int32_t n_links, const int32_t* links_bod
 int fmj_step(fmj_ctx* ctx, const fmj_data* d, int32_t n_steps, int64_t ctrl_step_stride,
              void* hip_stream);
 
+/* mj_forward without integration: fills xpos/xquat/xipos/sensordata/qacc for the current
+ * qpos/qvel.  disable_actuation=1 reproduces what dm_control runs after
+ * physics.reset(keyframe_id=0) (reference task.py:137): mj_forward with actuation disabled. */
+int fmj_forward(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, void* hip_stream);
+
 /* SwimmingHandler.step(iteration) (reference drag.pyx:389-411 -> drag_forces :152-268) for
  * every env: reads rows->links, writes rows->xfrc (rows of links above the surface are left
  * untouched, drag.pyx:192-194).  If xfrc_applied != NULL also performs the glue the reference

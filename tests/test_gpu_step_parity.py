@@ -1,0 +1,120 @@
+"""GPU parity: HIP fp32 step (through the C-ABI) vs the fp64 CPU oracle on identical inputs.
+
+The oracle is the checker only.  Tolerances are stated per test; north-star: qpos within 1e-4
+relative error after 1000 steps (fp64 -> fp32).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand_state(m, n, seed, qscale=0.3, vscale=0.5):
+    rng = np.random.default_rng(seed)
+    qpos = np.tile(m.qpos0, (n, 1))
+    qpos[:, 7:] += rng.uniform(-qscale, qscale, (n, m.nq - 7))
+    q = rng.normal(size=(n, 4)); qpos[:, 3:7] = q/np.linalg.norm(q, axis=1, keepdims=True)
+    qpos[:, :3] += rng.uniform(-0.2, 0.2, (n, 3))
+    qvel = rng.normal(size=(n, m.nv))*vscale
+    ctrl = rng.uniform(-0.5, 0.5, (n, m.nu))
+    return qpos, qvel, ctrl
+
+
+def _relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max()/max(np.abs(b).max(), 1e-12)
+
+
+@pytest.fixture(scope='module')
+def sal():
+    from farms_mujoco_amd.model import salamander33
+    return salamander33()
+
+
+def _gpu_physics(m, n):
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    return BatchedPhysics(m, n, 'cuda:0'), torch
+
+
+def test_single_step_all_fields(sal, oracle):
+    """One mj_step from random states: every output field <= 2e-5 relative (fp32 rounding)."""
+    m, n = sal, 64
+    phys, torch = _gpu_physics(m, n)
+    qpos, qvel, ctrl = _rand_state(m, n, 1)
+    xf = np.random.default_rng(2).normal(size=(n, m.nbody, 6))*0.01
+    xf[:, 0] = 0
+    d = phys.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    d.ctrl[:] = torch.as_tensor(ctrl, dtype=torch.float32); d.xfrc_applied[:] = torch.as_tensor(xf, dtype=torch.float32)
+    phys.step(1)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, qpos, qvel, ctrl=ctrl, xfrc_applied=xf)
+    assert int(d.status.abs().sum()) == 0
+    for name, tol in (('qpos', 2e-6), ('qvel', 2e-5), ('xpos', 2e-6), ('xquat', 2e-6), ('xipos', 2e-6),
+                      ('sensordata', 2e-5), ('qacc', 1e-4)):
+        err = _relerr(getattr(d, name).cpu().numpy(), ref[name])
+        assert err < tol, (name, err)
+
+
+def test_forward_only_matches_oracle_derived(sal, oracle):
+    """fmj_forward (no integration): derived fields equal the oracle's, state untouched."""
+    m, n = sal, 8
+    phys, torch = _gpu_physics(m, n)
+    qpos, qvel, ctrl = _rand_state(m, n, 3)
+    d = phys.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    q0 = d.qpos.clone(); v0 = d.qvel.clone()
+    phys.forward(disable_actuation=True)
+    torch.cuda.synchronize()
+    assert torch.equal(d.qpos, q0) and torch.equal(d.qvel, v0)
+    ref = oracle.step(m, qpos, qvel, ctrl=None)     # ctrl None -> zero ctrl; kp*q bias still acts in the oracle
+    for name in ('xpos', 'xquat', 'xipos'):
+        assert _relerr(getattr(d, name).cpu().numpy(), ref[name]) < 2e-6
+    # actuator forces are zero with actuation disabled
+    adr = phys.sensor_layout.actuatorfrc_adr
+    assert float(d.sensordata[:, adr:].abs().max()) == 0.0
+
+
+def test_thousand_steps_qpos(sal, oracle):
+    """North-star tolerance: qpos within 1e-4 relative error of the fp64 oracle after 1000 steps."""
+    m, n = sal, 32
+    phys, torch = _gpu_physics(m, n)
+    qpos, qvel, ctrl = _rand_state(m, n, 5, qscale=0.05, vscale=0.0)
+    qpos[:, :3] = m.qpos0[:3]; qpos[:, 3:7] = [1, 0, 0, 0]
+    rng = np.random.default_rng(6)
+    T = 1000
+    t = np.arange(T)[:, None, None]*m.timestep
+    jn = np.arange(m.nu)[None, None, :]
+    psi = rng.uniform(0, 2*np.pi, (1, n, 1))
+    tape = 0.3*np.sin(2*np.pi*1.0*t - 2*np.pi*(jn % 11)/11 + psi)
+    d = phys.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    # fp32-rounded inputs are THE inputs for both sides
+    qpos32 = d.qpos.cpu().numpy().astype(np.float64); qvel32 = d.qvel.cpu().numpy().astype(np.float64)
+    tape_t = torch.as_tensor(tape, dtype=torch.float32, device='cuda').contiguous()
+    tape32 = tape_t.cpu().numpy().astype(np.float64)
+    phys.step(T, ctrl_tape=tape_t)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, qpos32, qvel32, ctrl=tape32, n_steps=T, ctrl_step_stride=n*m.nu, n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    err = _relerr(d.qpos.cpu().numpy(), ref['qpos'])
+    print('qpos rel err after 1000 steps:', err)
+    assert err < 1e-4, err
+
+
+def test_batch_invariance_bitwise(sal):
+    """Env e's result is independent of batch size and position in the batch (bitwise)."""
+    m = sal
+    qpos, qvel, ctrl = _rand_state(m, 96, 9)
+    outs = []
+    for n, sl in ((96, slice(0, 96)), (17, slice(40, 57))):
+        phys, torch = _gpu_physics(m, n)
+        d = phys.data
+        d.qpos[:] = torch.as_tensor(qpos[sl], dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel[sl], dtype=torch.float32)
+        d.ctrl[:] = torch.as_tensor(ctrl[sl], dtype=torch.float32)
+        phys.step(20)
+        torch.cuda.synchronize()
+        outs.append((d.qpos.cpu().numpy().copy(), d.qvel.cpu().numpy().copy(), d.sensordata.cpu().numpy().copy()))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a[40:57], b)
