@@ -72,7 +72,7 @@ struct DevModel {
   const float4* a_prm;        // gain, bias0, bias1, bias2
   const float4* a_lim;        // ctrl lo, ctrl hi, force lo, force hi (+-FLT_MAX when unlimited)
   const int* a_src;
-  // M entries [nMpad]: i | j<<8 | depth<<16 | valid<<24 ; m_add = armature + h*damping on the diagonal
+  // M entries [nMpad]: i | j<<6 | depth<<12 | body(i)<<18 | valid<<24 ; m_add = armature + h*damping on the diagonal
   const uint32_t* m_tab;
   const float* m_add;
   // swimming [ns]: coeff(6), mass, height, density -> 3 float4
@@ -294,7 +294,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
 }
 
 template <bool FUSED>
-__global__ void __launch_bounds__(64) fmj_step_kernel(const DevModel M, const StepArgs A) {
+__global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
@@ -463,22 +463,34 @@ __global__ void __launch_bounds__(64) fmj_step_kernel(const DevModel M, const St
       q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
       const m33 Ri = q2m(qmul(xq, iq));
       const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
-      v3 d = sub3(xi, com);
-      ci[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2 + mass * (d.y * d.y + d.z * d.z);
-      ci[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2 + mass * (d.x * d.x + d.z * d.z);
-      ci[2] = Ri.a[6] * Ri.a[6] * i0 + Ri.a[7] * Ri.a[7] * i1 + Ri.a[8] * Ri.a[8] * i2 + mass * (d.x * d.x + d.y * d.y);
-      ci[3] = Ri.a[0] * Ri.a[3] * i0 + Ri.a[1] * Ri.a[4] * i1 + Ri.a[2] * Ri.a[5] * i2 - mass * d.x * d.y;
-      ci[4] = Ri.a[0] * Ri.a[6] * i0 + Ri.a[1] * Ri.a[7] * i1 + Ri.a[2] * Ri.a[8] * i2 - mass * d.x * d.z;
-      ci[5] = Ri.a[3] * Ri.a[6] * i0 + Ri.a[4] * Ri.a[7] * i1 + Ri.a[5] * Ri.a[8] * i2 - mass * d.y * d.z;
-      ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
+      // world-frame inertia about the body's own CoM
+      float iw[6];
+      iw[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2;
+      iw[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2;
+      iw[2] = Ri.a[6] * Ri.a[6] * i0 + Ri.a[7] * Ri.a[7] * i1 + Ri.a[8] * Ri.a[8] * i2;
+      iw[3] = Ri.a[0] * Ri.a[3] * i0 + Ri.a[1] * Ri.a[4] * i1 + Ri.a[2] * Ri.a[5] * i2;
+      iw[4] = Ri.a[0] * Ri.a[6] * i0 + Ri.a[1] * Ri.a[7] * i1 + Ri.a[2] * Ri.a[8] * i2;
+      iw[5] = Ri.a[3] * Ri.a[6] * i0 + Ri.a[4] * Ri.a[7] * i1 + Ri.a[5] * Ri.a[8] * i2;
       if (!isb) {
 #pragma unroll
-        for (int k = 0; k < 10; k++) ci[k] = 0.f;
+        for (int k = 0; k < 6; k++) iw[k] = 0.f;
       }
+      // cinert about the tree CoM (MuJoCo's form) stays in registers for the RNE part
+      v3 d = sub3(xi, com);
+      ci[0] = iw[0] + mass * (d.y * d.y + d.z * d.z);
+      ci[1] = iw[1] + mass * (d.x * d.x + d.z * d.z);
+      ci[2] = iw[2] + mass * (d.x * d.x + d.y * d.y);
+      ci[3] = iw[3] - mass * d.x * d.y;
+      ci[4] = iw[4] - mass * d.x * d.z;
+      ci[5] = iw[5] - mass * d.y * d.z;
+      ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
       if (lane < nb) {
-        *(float4*)(CI + lane * 12) = make_float4(ci[0], ci[1], ci[2], ci[3]);
-        *(float4*)(CI + lane * 12 + 4) = make_float4(ci[4], ci[5], ci[6], ci[7]);
-        *(float2*)(CI + lane * 12 + 8) = make_float2(ci[8], ci[9]);
+        // LDS gets the LOCAL description (inertia about the body's own CoM, CoM, mass): S assembles
+        // each composite inertia about its own subtree CoM, which avoids the m*d^2 inflation (and the
+        // fp32 cancellation it causes in M) of inertias taken about the distant tree CoM.
+        *(float4*)(CI + lane * 12) = make_float4(iw[0], iw[1], iw[2], iw[3]);
+        *(float4*)(CI + lane * 12 + 4) = make_float4(iw[4], iw[5], xi.x, xi.y);
+        *(float2*)(CI + lane * 12 + 8) = make_float2(xi.z, mass);
       }
     }
     s6 vJ = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
@@ -529,42 +541,60 @@ __global__ void __launch_bounds__(64) fmj_step_kernel(const DevModel M, const St
       if (lane < nb) lds_put6(F + lane * 8, f);     // T region: all chain reads completed before the last WSYNC
     }
     WSYNC();
-    // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize)
+    // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize): accumulated force
+    // (about the tree CoM) and composite inertia taken about the body's own CoM, then shifted to
+    // the subtree CoM s (all lever arms are local to the subtree).
     {
-      float crb[10]; s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+      float cm = 0.f; v3 mr = mk3(0.f, 0.f, 0.f);
+      float ic[6];
+      s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
 #pragma unroll
-      for (int k = 0; k < 10; k++) crb[k] = 0.f;
+      for (int k = 0; k < 6; k++) ic[k] = 0.f;
       for (int k = 0; k < M.max_subsize; k++) {
         if (k < bsub) {
           const int d = lane + k;
           float4 a = *(const float4*)(CI + d * 12), b = *(const float4*)(CI + d * 12 + 4);
           float2 c = *(const float2*)(CI + d * 12 + 8);
-          crb[0] += a.x; crb[1] += a.y; crb[2] += a.z; crb[3] += a.w;
-          crb[4] += b.x; crb[5] += b.y; crb[6] += b.z; crb[7] += b.w; crb[8] += c.x; crb[9] += c.y;
+          const float md = c.y;
+          v3 rr = sub3(mk3(b.z, b.w, c.x), xi);
+          cm += md; mr = add3(mr, scl3(rr, md));
+          ic[0] += a.x + md * (rr.y * rr.y + rr.z * rr.z);
+          ic[1] += a.y + md * (rr.x * rr.x + rr.z * rr.z);
+          ic[2] += a.z + md * (rr.x * rr.x + rr.y * rr.y);
+          ic[3] += a.w - md * rr.x * rr.y;
+          ic[4] += b.x - md * rr.x * rr.z;
+          ic[5] += b.y - md * rr.y * rr.z;
           fs = s6add(fs, lds_get6(F + d * 8));
         }
       }
+      const float cminv = cm > 0.f ? 1.0f / cm : 0.f;
+      const v3 dl = scl3(mr, cminv);                 // subtree CoM relative to this body's CoM
+      const v3 sc = add3(xi, dl);
+      ic[0] -= cm * (dl.y * dl.y + dl.z * dl.z); ic[1] -= cm * (dl.x * dl.x + dl.z * dl.z); ic[2] -= cm * (dl.x * dl.x + dl.y * dl.y);
+      ic[3] += cm * dl.x * dl.y; ic[4] += cm * dl.x * dl.z; ic[5] += cm * dl.y * dl.z;
       WSYNC();
       if (lane < nb) {
-        *(float4*)(CI + lane * 12) = make_float4(crb[0], crb[1], crb[2], crb[3]);
-        *(float4*)(CI + lane * 12 + 4) = make_float4(crb[4], crb[5], crb[6], crb[7]);
-        *(float2*)(CI + lane * 12 + 8) = make_float2(crb[8], crb[9]);
+        *(float4*)(CI + lane * 12) = make_float4(ic[0], ic[1], ic[2], ic[3]);
+        *(float4*)(CI + lane * 12 + 4) = make_float4(ic[4], ic[5], sc.x, sc.y);
+        *(float2*)(CI + lane * 12 + 8) = make_float2(sc.z, cm);
         lds_put6(F + lane * 8, fs);
       }
     }
     WSYNC();
-    // ---- Q: qfrc_smooth, buf = crb*cdof  (lane = dof)
+    // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
     if (isd) {
       const int body = d_info.x;
       s6 cd = lds_get6(CD + lane * 8);
-      float crb[10];
       {
         float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
         float2 c = *(const float2*)(CI + body * 12 + 8);
-        crb[0] = a.x; crb[1] = a.y; crb[2] = a.z; crb[3] = a.w; crb[4] = b.x; crb[5] = b.y; crb[6] = b.z; crb[7] = b.w; crb[8] = c.x; crb[9] = c.y;
+        v3 vs = add3(cd.l, cross(cd.r, sub3(mk3(b.z, b.w, c.x), com)));   // velocity of the subtree CoM per unit dof rate
+        s6 bf;
+        bf.r = mk3(a.x * cd.r.x + a.w * cd.r.y + b.x * cd.r.z, a.w * cd.r.x + a.y * cd.r.y + b.y * cd.r.z, b.x * cd.r.x + b.y * cd.r.y + a.z * cd.r.z);
+        bf.l = scl3(vs, c.y);
+        lds_put6(BUF + lane * 8, bf);   // V region: chain reads completed two WSYNCs ago
       }
-      lds_put6(BUF + lane * 8, inert_mul(crb, cd));   // V region: chain reads completed two WSYNCs ago
       const float qd = QV[lane];
       qfrc = -d_prm.y * qd - s6dot(cd, lds_get6(F + body * 8));
       if (d_scalar) {
@@ -602,23 +632,29 @@ __global__ void __launch_bounds__(64) fmj_step_kernel(const DevModel M, const St
       }
     }
     WSYNC();
-    // ---- M: H entries, one per lane per round
+    // ---- M: H entries, one per lane per round: M_ij = w_j . (I_s w_i) + v_j(s) . (m v_i(s)), s = subtree CoM of dof i's body
     for (int e = lane; e < M.nMpad; e += 64) {
       const uint32_t t = M.m_tab[e];
       if (t >> 24) {
-        const int i = t & 0xff, j = (t >> 8) & 0xff, dep = (t >> 16) & 0xff;
-        HR[i * RS + dep] = s6dot(lds_get6(CD + j * 8), lds_get6(BUF + i * 8)) + M.m_add[e];
+        const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
+        const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
+        const float2 sxy = *(const float2*)(CI + body * 12 + 6);
+        const float sz = CI[body * 12 + 8];
+        const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
+        HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + M.m_add[e];
       }
     }
     WSYNC();
     // ---- L: L'DL with register rows, pivot row k broadcast through LDS.
-    // Padding slots (depth index > own depth) are zero and stay zero: 0 - t*0.
     float r[FMJ_MAXD];
 #pragma unroll
     for (int d = 0; d < FMJ_MAXD; d += 4) {
       float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
       if (d < RS && isd) t = *(const float4*)(HR + lane * RS + d);
-      r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
+      // slots past the lane's own depth collect -t*rk garbage during elimination: never read as
+      // matrix entries, but they must not carry over from step to step (they would grow by 1/D each step)
+      r[d] = d <= ddepth ? t.x : 0.f; r[d + 1] = d + 1 <= ddepth ? t.y : 0.f;
+      r[d + 2] = d + 2 <= ddepth ? t.z : 0.f; r[d + 3] = d + 3 <= ddepth ? t.w : 0.f;
     }
     float dinv_mine = 0.f;
     for (int k = nv - 1; k >= 0; k--) {
@@ -975,7 +1011,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   for (int i = 0; i < nv; i++) {
     if (m->dof_Madr[i] != e) { fmj_destroy(c); return set_err(FMJ_ERR_ARG, "fmj_create: dof_Madr inconsistent"); }
     for (int j = i; j >= 0; j = m->dof_parentid[j]) {
-      m_tab[e] = (uint32_t)i | ((uint32_t)j << 8) | ((uint32_t)ddepth[j] << 16) | (1u << 24);
+      m_tab[e] = (uint32_t)i | ((uint32_t)j << 6) | ((uint32_t)ddepth[j] << 12) | ((uint32_t)m->dof_bodyid[i] << 18) | (1u << 24);
       if (i == j) m_add[e] = (float)(m->dof_armature[i] + m->timestep * m->dof_damping[i]);
       e++;
     }

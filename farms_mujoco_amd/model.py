@@ -606,8 +606,12 @@ def salamander33(contacts: bool = False, limits: bool = False, full_actuators: b
             parent = f'body_{attach}'
             for k, ax in enumerate(((0, 0, 1), (0, 1, 0), (1, 0, 0))):
                 name = f'{base}_{k}'
+                # SURVEY Appendix D suggests 1e-8 kg m^2 here with kp = 1: that puts a mode at
+                # omega*h = 10 (two parallel pitch joints around a near-massless link), unstable for any
+                # explicit position actuator at h = 1e-3, MuJoCo included. 1e-6 and kp = 0.1 on the limbs
+                # keep every actuator mode below omega*h = 1.4.
                 b.add_body(name, parent, pos=(L/2, side*0.025, 0) if k == 0 else (0, 0, 0), mass=1e-3,
-                           inertia=(1e-8, 1e-8, 1e-8), joint='hinge', jname=f'joint_{name}', axis=ax,
+                           inertia=(1e-6, 1e-6, 1e-6), joint='hinge', jname=f'joint_{name}', axis=ax,
                            damping=1e-4, limited=limits, range=rng)
                 b.set_swimming(name, density=1000.0, drag_coefficients=[[-1e-3]*3, [-1e-6]*3], height=0.5*0.005)
                 parent = name
@@ -629,10 +633,11 @@ def salamander33(contacts: bool = False, limits: bool = False, full_actuators: b
         b.options['max_contacts'] = 32
     for jn in [f'joint_body_{i}' for i in range(1, n_spine)] + [
             f'joint_leg_{t}_{s}_{k}' for t in ('front', 'hind') for s in ('L', 'R') for k in range(4)]:
+        kp = 1.0 if jn.startswith('joint_body_') else 0.1
         if full_actuators:
-            b.add_joint_actuators(jn, kp=1.0, kv=0.0)
+            b.add_joint_actuators(jn, kp=kp, kv=0.0)
         else:
-            b.add_position_actuator(jn, kp=1.0)
+            b.add_position_actuator(jn, kp=kp)
     return b.compile()
 
 
@@ -679,14 +684,44 @@ def centipede(n_segments: int = 10, n_spine_joints: int = 15, timestep: float = 
             for side, sname in ((+1, 'L'), (-1, 'R')):
                 up = f'leg_{i}_{sname}_0'
                 lo = f'leg_{i}_{sname}_1'
-                b.add_body(up, f'body_{i}', pos=(L/2, side*r, 0), mass=2e-4, inertia=(2e-9,)*3, joint='hinge',
+                b.add_body(up, f'body_{i}', pos=(L/2, side*r, 0), mass=2e-4, inertia=(5e-7,)*3, joint='hinge',
                            jname=f'joint_{up}', axis=(0, 0, 1), damping=5e-5)
                 lm = 1000.0*np.pi*0.0015**2*0.015
                 b.add_body(lo, up, pos=(0, side*0.004, 0), mass=lm, ipos=(0, side*0.0075, 0),
-                           inertia=(lm*0.015**2/12, 1e-10, lm*0.015**2/12), joint='hinge', jname=f'joint_{lo}',
+                           inertia=(lm*0.015**2/12 + 2e-7, 2e-7, lm*0.015**2/12 + 2e-7), joint='hinge', jname=f'joint_{lo}',
                            axis=(1, 0, 0), damping=5e-5)
                 b.set_swimming(up, drag_coefficients=[[-1e-4]*3, [-1e-7]*3], height=0.001)
                 b.set_swimming(lo, drag_coefficients=[[-0.02, -0.0002, -0.02], [-1e-7]*3], height=0.004)
     for jn in [x for x in [bd.joint['name'] for bd in b.bodies[1:] if bd.joint] if not x.startswith('root_')]:
-        b.add_position_actuator(jn, kp=0.2)
+        b.add_position_actuator(jn, kp=0.2 if jn.startswith('joint_body_') else 0.05)
     return b.compile()
+
+
+def wave_controller_params(m: Model, amplitude: float = 0.3, n_wave: float = 1.0):
+    """Per-actuator amplitude / phase lag of the travelling-wave position controller used by the
+    benchmark configs: A on the axial (``joint_body_*``) position actuators with
+    phase lag 2*pi*n_wave*j/n_axial, zero elsewhere (limbs held, velocity/motor actuators idle)."""
+    amp = np.zeros(m.nu)
+    lag = np.zeros(m.nu)
+    axial = [j for j, n in enumerate(m.joint_names) if n.startswith('joint_body_')]
+    for a in range(m.nu):
+        j = int(m.actuator_jntid[a])
+        if m.actuator_tags[a] == 'position' and j in axial:
+            amp[a] = amplitude
+            lag[a] = 2*np.pi*n_wave*axial.index(j)/len(axial)
+    return amp, lag
+
+
+def synthetic_batch(m: Model, n_envs: int, seed: int = 0, env_offset: int = 0, perturb: float = 0.05):
+    """Deterministic per-env initial state + controller phase keyed by GLOBAL env index (so sharding a
+    batch over GPUs does not change any env's inputs): hinge qpos perturbation ~U(-p,p),
+    phase psi ~U[0,2pi)."""
+    qpos = np.tile(m.key_qpos, (n_envs, 1))
+    psi = np.zeros(n_envs)
+    hinge_q = m.jnt_qposadr[m.jnt_type != JNT_FREE]
+    for e in range(n_envs):
+        rng = np.random.default_rng([seed, env_offset + e])
+        qpos[e, hinge_q] += rng.uniform(-perturb, perturb, len(hinge_q))
+        psi[e] = rng.uniform(0, 2*np.pi)
+    qvel = np.zeros((n_envs, m.nv))
+    return qpos, qvel, psi

@@ -956,7 +956,8 @@ static void* step_worker(void* arg) {
     if (J->xquat) memcpy(J->xquat + (size_t)e * m->nbody * 4, w->xquat, 4 * m->nbody * sizeof(double));
     if (J->xipos) memcpy(J->xipos + (size_t)e * m->nbody * 3, w->xipos, 3 * m->nbody * sizeof(double));
     if (J->sensordata) memcpy(J->sensordata + (size_t)e * J->nsd, sd, J->nsd * sizeof(double));
-    if (J->qacc) memcpy(J->qacc + (size_t)e * m->nv, w->qacc, m->nv * sizeof(double));
+    /* the acceleration Euler actually integrated ((M+hB)^-1 f when any damping > 0), NOT mjData.qacc */
+    if (J->qacc) memcpy(J->qacc + (size_t)e * m->nv, w->tmpv, m->nv * sizeof(double));
     if (J->status) J->status[e] |= warn;
   }
   free(sd); ws_free(w);
