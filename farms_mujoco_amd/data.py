@@ -1,0 +1,84 @@
+"""AnimatData stand-in (farms_core.model.data.AnimatData is not in the reference tree).
+
+Ring-buffer sensor log the reference writes every iteration (reference task.py:62,158,208-216):
+``data.sensors.{links,joints,xfrc,contacts}.array`` with shape ``[buffer_size, n_envs, n, width]`` —
+the reference's ``[buffer_size, n, width]`` with an env axis inserted after the ring index, so
+``array[index]`` is one contiguous slab written by one launch.  Column integers come from the HIP
+library (``fmj_sc``), never hard-coded here.
+"""
+from types import SimpleNamespace
+
+import torch
+
+from . import _lib
+
+
+class _SC:
+    """Column convention namespace (farms_core ``sc``; reference physics.py:427-523)."""
+    _names = {
+        'link_com_position_x': ('LINK_COM_POS', 0), 'link_com_position_y': ('LINK_COM_POS', 1),
+        'link_com_position_z': ('LINK_COM_POS', 2),
+        'link_com_orientation_x': ('LINK_COM_QUAT', 0), 'link_com_orientation_w': ('LINK_COM_QUAT', 3),
+        'link_urdf_position_x': ('LINK_URDF_POS', 0), 'link_urdf_position_z': ('LINK_URDF_POS', 2),
+        'link_urdf_orientation_x': ('LINK_URDF_QUAT', 0), 'link_urdf_orientation_w': ('LINK_URDF_QUAT', 3),
+        'link_com_velocity_lin_x': ('LINK_COM_LINVEL', 0), 'link_com_velocity_lin_z': ('LINK_COM_LINVEL', 2),
+        'link_com_velocity_ang_x': ('LINK_COM_ANGVEL', 0), 'link_com_velocity_ang_z': ('LINK_COM_ANGVEL', 2),
+        'link_size': ('LINK_SIZE', 0),
+        'joint_position': ('JOINT_POSITION', 0), 'joint_velocity': ('JOINT_VELOCITY', 0),
+        'joint_force_x': ('JOINT_FORCE', 0), 'joint_force_z': ('JOINT_FORCE', 2),
+        'joint_torque_x': ('JOINT_TORQUE3', 0), 'joint_torque_z': ('JOINT_TORQUE3', 2),
+        'joint_torque': ('JOINT_TORQUE', 0), 'joint_limit_force': ('JOINT_LIMIT_FORCE', 0),
+        'joint_size': ('JOINT_SIZE', 0),
+        'contact_reaction_x': ('CONTACT_REACTION', 0), 'contact_friction_x': ('CONTACT_FRICTION', 0),
+        'contact_total_x': ('CONTACT_TOTAL', 0), 'contact_position_x': ('CONTACT_POSITION', 0),
+        'contact_size': ('CONTACT_SIZE', 0),
+        'xfrc_force_x': ('XFRC_FORCE', 0), 'xfrc_torque_x': ('XFRC_TORQUE', 0), 'xfrc_size': ('XFRC_SIZE', 0),
+    }
+
+    def __getattr__(self, name):
+        try:
+            base, off = self._names[name]
+        except KeyError as e:
+            raise AttributeError(name) from e
+        return _lib.sc(base) + off
+
+
+sc = _SC()
+
+
+class SensorArray:
+    def __init__(self, names, array):
+        self.names = list(names)
+        self.array = array
+
+
+class AnimatData:
+    def __init__(self, timestep, buffer_size, n_envs, links, joints, xfrc=None, contacts=(), device='cuda:0'):
+        self.timestep = timestep
+        self.buffer_size = buffer_size
+        self.n_envs = n_envs
+        z = lambda n, w: torch.zeros(buffer_size, n_envs, max(n, 1), w, dtype=torch.float32, device=device)[:, :, :n]
+        xfrc = list(links) if xfrc is None else list(xfrc)
+        self.sensors = SimpleNamespace(
+            links=SensorArray(links, z(len(links), sc.link_size)),
+            joints=SensorArray(joints, z(len(joints), sc.joint_size)),
+            xfrc=SensorArray(xfrc, z(len(xfrc), sc.xfrc_size)),
+            contacts=SensorArray(contacts, z(len(contacts), sc.contact_size)),
+            muscles=SensorArray([], z(0, 1)),
+        )
+        self.sensors.links.masses = None
+
+    @classmethod
+    def from_sensors_names(cls, timestep, buffer_size, links, joints, n_envs=1, device='cuda:0', **kwargs):
+        """reference task.py:208-216 (``muscles`` accepted and ignored: out of scope)."""
+        kwargs.pop('muscles', None)
+        return cls(timestep, buffer_size, n_envs, links, joints, device=device, **kwargs)
+
+    def to_file(self, path, iteration=None):
+        """Post-hoc log (reference simulation.py:200-203 writes HDF5; h5py is absent here -> .npz)."""
+        import numpy as np
+        n = self.buffer_size if iteration is None else min(iteration, self.buffer_size)
+        np.savez_compressed(path, timestep=self.timestep,
+                            **{k: getattr(self.sensors, k).array[:n].cpu().numpy()
+                               for k in ('links', 'joints', 'xfrc', 'contacts')},
+                            links_names=self.sensors.links.names, joints_names=self.sensors.joints.names)

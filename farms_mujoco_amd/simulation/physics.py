@@ -1,0 +1,51 @@
+"""Physics readout — counterpart of reference farms_mujoco/simulation/physics.py."""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..model import JNT_FREE
+
+
+def get_sensor_maps(physics, verbose=False):
+    """Sensor-name -> sensordata index maps (reference physics.py:64-185), by the same name prefixes."""
+    names = physics.model.sensor_names()
+    widths = [3 if n.startswith(('framelinvel', 'frameangvel')) else 1 for n in names]
+    adr = np.concatenate([[0], np.cumsum(widths)])
+    sensors = ['framepos', 'framequat', 'framelinvel', 'frameangvel', 'jointpos', 'jointvel', 'jointlimitfrc',
+               'force', 'torque', 'actuatorfrc_position', 'actuatorfrc_velocity', 'actuatorfrc_torque', 'touch']
+    maps = {}
+    for s in sensors:
+        idx = [i for i, n in enumerate(names) if n.startswith(s)]
+        maps[s] = {'names': [names[i] for i in idx],
+                   'indices': np.array([np.arange(adr[i], adr[i + 1]) for i in idx])}
+    return maps
+
+
+def get_physics2data_maps(physics, sensor_data, sensor_maps):
+    """Row maps from AnimatData names to bodies / joints (reference physics.py:188-393); uploads them to
+    the HIP context (fmj_set_readout_maps)."""
+    m = physics.model
+    links_body = np.array([m.body_names.index(n) for n in sensor_data.links.names], np.int32)
+    joints_jnt = np.array([m.joint_names.index(n) for n in sensor_data.joints.names], np.int32)
+    assert all(m.jnt_type[j] != JNT_FREE for j in joints_jnt), 'joint rows must be hinge/slide joints'
+    sensor_maps['xpos2data'] = sensor_maps['xquat2data'] = sensor_maps['xipos2data'] = links_body
+    sensor_maps['qpos2data'] = m.jnt_qposadr[joints_jnt]
+    sensor_maps['qvel2data'] = m.jnt_dofadr[joints_jnt]
+    sensor_maps['datalinks2xfrc'] = links_body
+    sensor_maps['data2xfrc'] = np.array([m.body_names.index(n) for n in sensor_data.xfrc.names], np.int32)
+    physics.set_readout_maps(links_body, joints_jnt)
+    return sensor_maps
+
+
+def physics2data(physics, iteration, data, maps, units, links_only=False):
+    """Sensors data collection for every env (reference physics.py:527-545) -> C-ABI fmj_physics2data."""
+    rows = _lib.CRows()
+    rows.links = data.sensors.links.array[iteration].data_ptr()
+    rows.joints = data.sensors.joints.array[iteration].data_ptr()
+    c = physics._cdata()
+    u = units.as_c()
+    _lib.check(physics._lib.fmj_physics2data(physics._ctx, ctypes.byref(c), ctypes.byref(rows), ctypes.byref(u),
+                                             int(links_only),
+                                             ctypes.c_void_p(torch.cuda.current_stream(physics.device).cuda_stream)))

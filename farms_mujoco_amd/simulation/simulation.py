@@ -1,0 +1,166 @@
+"""Simulation — counterpart of reference farms_mujoco/simulation/simulation.py."""
+import ctypes
+import os
+import traceback
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..model import Model
+from ..options import AnimatOptions, ArenaOptions, SimulationOptions
+from ..physics import BatchedPhysics, PhysicsError
+from .task import ExperimentTask, SwimmingCallback
+
+import logging
+pylog = logging.getLogger('farms_mujoco_amd')
+
+
+def extract_sub_dict(dictionary: Dict, keys: List[str]) -> Dict:
+    """Extract sub-dictionary"""
+    return {key: dictionary.pop(key) for key in keys if key in dictionary}
+
+
+class Simulation:
+    """Batched simulation with the reference's API shape (reference simulation.py:33-213).
+
+    ``mjcf_model`` is a compiled :class:`~farms_mujoco_amd.model.Model` (the dm_control MJCF element tree is
+    replaced).  Extra kwargs: ``n_envs``, ``device``.  ``legacy_step`` is accepted for signature
+    compatibility; the step is always the full mj_step (legacy_step=False semantics, simulation.py:36-37).
+    Unlike dm_control's Environment, whose first ``step()`` only resets, ``run()`` here
+    advances exactly ``n_iterations * substeps`` physics steps after an explicit :meth:`reset`.
+    """
+
+    def __init__(self, mjcf_model: Model, base_link: str, simulation_options: SimulationOptions,
+                 legacy_step: bool = False, **kwargs):
+        self._mjcf_model = mjcf_model
+        self.options = simulation_options
+        self.pause = not self.options.play
+        n_envs = kwargs.pop('n_envs', 1)
+        device = kwargs.pop('device', 'cuda:0')
+        self.physics = BatchedPhysics(mjcf_model, n_envs, device)
+        self.handle_exceptions = kwargs.pop('handle_exceptions', False)
+        extract_sub_dict(kwargs, ('control_timestep', 'n_sub_steps', 'flat_observation'))
+        self.task = ExperimentTask(base_link=base_link, n_iterations=self.options.n_iterations,
+                                   timestep=self.options.timestep, units=self.options.units,
+                                   substeps=self.options.num_sub_steps, **kwargs)
+        self._needs_reset = True
+
+    @property
+    def iteration(self):
+        """Iteration"""
+        return self.task.iteration
+
+    @classmethod
+    def from_sdf(cls, simulation_options, animat_options, arena_options, **kwargs):
+        """From SDF (reference simulation.py:96-124).  The SDF -> model compiler is the next row of the
+        scope table; pass a pre-built model as ``model=`` meanwhile."""
+        model = kwargs.pop('model', None)
+        if model is None:
+            raise NotImplementedError('SDF -> model compilation is not part of the hot path yet; pass model=')
+        extract_sub_dict(kwargs, ('spawn_position', 'spawn_rotation', 'save_mjcf', 'use_particles'))
+        callbacks = kwargs.pop('callbacks', [])
+        water = getattr(arena_options, 'water', None)
+        if water is not None and water.height is not None and (water.drag or water.sph) \
+                and not any(isinstance(cb, SwimmingCallback) for cb in callbacks):
+            callbacks = [SwimmingCallback(animat_options, arena_options)] + list(callbacks)
+        return cls(mjcf_model=model, base_link=model.body_names[1], simulation_options=simulation_options,
+                   animat_options=animat_options, callbacks=callbacks, **kwargs)
+
+    def reset(self):
+        self.task.initialize_episode(self.physics)
+        self._needs_reset = False
+
+    # ---- stepping ---------------------------------------------------------------------------------------
+    def _env_step(self):
+        """Environment.step(action=None): before_step -> physics.step -> after_step."""
+        self.task.before_step(None, self.physics)
+        self.physics.step(1)
+        self.task.after_step(self.physics)
+
+    def step_fused(self, n_steps: int):
+        """Run ``n_steps`` full iterations inside ONE launch (fmj_step_fused): ring-buffer readout, drag,
+        xfrc glue, controller and mj_step, with state resident in LDS/registers between steps."""
+        task, phys = self.task, self.physics
+        assert task.fusable()
+        n_steps = min(n_steps, task.n_iterations - task.iteration)
+        if n_steps <= 0:
+            return 0
+        a = _lib.CFusedArgs()
+        a.n_steps, a.iteration0, a.buffer_size = n_steps, task.iteration, task.buffer_size
+        a.do_readout = 1
+        sens = task.data.sensors
+        a.rows_base.links = sens.links.array.data_ptr()
+        a.rows_base.joints = sens.joints.array.data_ptr()
+        a.rows_base.xfrc = sens.xfrc.array.data_ptr()
+        a.row_stride_links = sens.links.array.stride(0)
+        a.row_stride_joints = sens.joints.array.stride(0)
+        a.row_stride_xfrc = sens.xfrc.array.stride(0)
+        swim = [cb for cb in task._callbacks if isinstance(cb, SwimmingCallback)]
+        a.do_drag = int(bool(swim) and swim[0].handler.drag)
+        if swim:
+            h = swim[0].handler
+            a.water = h.water.as_c(use_buoyancy=h.buoyancy)
+        a.units = task.units.as_c()
+        c = task._controller
+        if c is not None:
+            a.controller = 1
+            a.wave.amplitude, a.wave.phase_lag, a.wave.env_phase = (c.amplitude.data_ptr(), c.phase_lag.data_ptr(),
+                                                                     c.env_phase.data_ptr())
+            a.wave.frequency = c.frequency
+        cd = phys._cdata()
+        _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
+                                            ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
+        task.iteration += n_steps
+        task.sim_iteration += n_steps
+        return n_steps
+
+    def run(self, fused=None, chunk=None):
+        """Run simulation (headless loop of reference simulation.py:148-161)."""
+        if self._needs_reset:
+            self.reset()
+        task = self.task
+        fused = task.fusable() if fused is None else fused
+        try:
+            if fused:
+                chunk = chunk or task.buffer_size
+                while task.iteration < task.n_iterations:
+                    self.step_fused(min(chunk, task.buffer_size))
+            else:
+                for _ in range(task.sim_iterations - task.sim_iteration):
+                    self._env_step()
+            self.physics.check_invalid_state()
+        except PhysicsError as err:
+            pylog.error(traceback.format_exc())
+            if self.handle_exceptions:
+                return
+            raise err
+        pylog.info('Closing simulation')
+
+    def iterator(self, show_progress: bool = True, verbose: bool = True):
+        """Run simulation, yielding each iteration to the caller first (reference simulation.py:164-179)."""
+        if self._needs_reset:
+            self.reset()
+        try:
+            for iteration in range(self.task.n_iterations):
+                yield iteration
+                for _ in range(self.task.substeps):
+                    self._env_step()
+            self.physics.check_invalid_state()
+        except PhysicsError as err:
+            if verbose:
+                pylog.error(traceback.format_exc())
+            raise err
+
+    def postprocess(self, iteration: int, log_path: str = '', plot: bool = False, **kwargs):
+        """Postprocessing after simulation (reference simulation.py:181-213)."""
+        if log_path:
+            pylog.info('Saving data to %s', log_path)
+            self.task.data.to_file(os.path.join(log_path, 'simulation.npz'), iteration)
+            self.options.save(os.path.join(log_path, 'simulation_options.yaml'))
+            if self.task.animat_options is not None:
+                self.task.animat_options.save(os.path.join(log_path, 'animat_options.yaml'))
+
+    def save_mjcf_xml(self, path: str, verbose: bool = False):
+        raise NotImplementedError('MJCF export belongs to the model-compiler row (SURVEY §8 f1)')

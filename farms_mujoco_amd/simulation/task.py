@@ -1,0 +1,193 @@
+"""Task — counterpart of reference farms_mujoco/simulation/task.py (same hooks, batched tensors)."""
+from typing import Dict, List
+
+import numpy as np
+import torch
+
+from ..control import ControlType
+from ..data import AnimatData
+from ..units import SimulationUnitScaling as SimulationUnits
+from .physics import get_sensor_maps, get_physics2data_maps, physics2data
+
+
+def duration2nit(duration: float, timestep: float) -> int:
+    """Number of iterations from duration"""
+    return int(duration/timestep)
+
+
+class TaskCallback:
+    """Task callback (reference task.py:415-446): identical hooks; ``physics`` is the batched physics."""
+
+    def __init__(self, substep=False):
+        self.substep = substep
+
+    def initialize_episode(self, task, physics): """Initialize episode"""
+    def before_step(self, task, action, physics): """Before step"""
+    def after_step(self, task, physics): """After step"""
+    def action_spec(self, task, physics): """Action specifications"""
+    def step_spec(self, task, physics): """Timestep specifications"""
+    def get_observation(self, task, physics): """Environment observation"""
+    def get_reward(self, task, physics): """Reward"""
+    def get_termination(self, task, physics): """Return final discount if episode should end, else None"""
+    def observation_spec(self, task, physics): """Observation specifications"""
+
+
+class SwimmingCallback(TaskCallback):
+    """The swimming callback the reference leaves to external packages: constructs the
+    SwimmingHandler at episode start and, before every step, computes drag from the links row and writes
+    ``physics.data.xfrc_applied`` (world frame, unit-scaled)."""
+    fusable = True
+
+    def __init__(self, animat_options, arena_options, substep=False):
+        super().__init__(substep=substep)
+        self.animat_options = animat_options
+        self.arena_options = arena_options
+        self.handler = None
+
+    def initialize_episode(self, task, physics):
+        from ..swimming.drag import SwimmingHandler
+        self.handler = SwimmingHandler(task.data, self.animat_options, self.arena_options, task.units, physics)
+
+    def before_step(self, task, action, physics):
+        self.handler.step(task.iteration % task.buffer_size)
+
+
+class ExperimentTask:
+    """FARMS experiment (reference task.py:37-412)."""
+
+    def __init__(self, base_link: str, n_iterations: int, timestep: float, **kwargs):
+        self.iteration: int = 0
+        self.timestep: float = timestep
+        self.n_iterations: int = n_iterations
+        self.base_link: str = base_link
+        self.data: AnimatData = kwargs.pop('data', None)
+        self._controller = kwargs.pop('controller', None)
+        self.animat_options = kwargs.pop('animat_options', None)
+        self.external_force: float = kwargs.pop('external_force', 0.2)
+        self._restart: bool = kwargs.pop('restart', False)
+        self._callbacks: List[TaskCallback] = kwargs.pop('callbacks', [])
+        self._extras: Dict = {'hfield': kwargs.pop('hfield', None)}
+        self.units: SimulationUnits = kwargs.pop('units', SimulationUnits())
+        self.substeps = max(1, kwargs.pop('substeps', 1))
+        self.buffer_size = max(1, kwargs.pop('buffer_size', 1))
+        self.substeps_links = any(cb.substep for cb in self._callbacks)
+        self.sim_iteration = 0
+        self.sim_iterations = self.n_iterations*self.substeps
+        self.sim_timestep = self.timestep/self.substeps
+        self.maps: Dict = {'sensors': {}, 'ctrl': {}, 'xpos': {}, 'qpos': {}, 'geoms': {}, 'links': {},
+                           'joints': {}, 'contacts': {}, 'xfrc': {}, 'muscles': {}}
+        assert not kwargs, kwargs
+
+    # ---- episode ---------------------------------------------------------------------------------
+    def initialize_episode(self, physics):
+        """Sets the state of the environment at the start of each episode (reference task.py:87-154)."""
+        self.iteration = 0
+        self.sim_iteration = 0
+        self.initialize_maps(physics)
+        if self.data is None:
+            self.initialize_data(physics)
+        self.data.sensors.links.masses = np.array(
+            [physics.model.body_mass[physics.model.body_names.index(n)] for n in self.data.sensors.links.names],
+            dtype=float)/self.units.kilograms
+        self.initialize_sensors(physics)
+        if self._controller is not None:
+            self.initialize_control(physics)
+        physics.reset(keyframe_id=0)
+        for callback in self._callbacks:
+            callback.initialize_episode(task=self, physics=physics)
+
+    def initialize_maps(self, physics):
+        m = physics.model
+        self.maps['xpos']['names'] = m.body_names[1:]
+        self.maps['qpos']['names'] = m.hinge_joint_names()
+        self.maps['xfrc']['names'] = m.body_names[1:]
+
+    def initialize_data(self, physics):
+        self.data = AnimatData.from_sensors_names(timestep=self.timestep, buffer_size=self.buffer_size,
+                                                  links=self.maps['xpos']['names'], joints=self.maps['qpos']['names'],
+                                                  n_envs=physics.n_envs, device=physics.device)
+
+    def initialize_sensors(self, physics):
+        self.maps['sensors'] = get_sensor_maps(physics)
+        get_physics2data_maps(physics=physics, sensor_data=self.data.sensors, sensor_maps=self.maps['sensors'])
+
+    def initialize_control(self, physics):
+        """ctrl index maps (reference task.py:227-286)."""
+        m = physics.model
+        names = m.actuator_names
+        dev = physics.device
+        jn = self._controller.joints_names
+        self.maps['ctrl']['pos'] = torch.as_tensor([names.index(f'actuator_position_{j}') for j in jn[ControlType.POSITION]], device=dev)
+        self.maps['ctrl']['vel'] = torch.as_tensor([names.index(f'actuator_velocity_{j}') for j in jn[ControlType.VELOCITY]], device=dev)
+        self.maps['ctrl']['trq'] = torch.as_tensor([names.index(f'actuator_torque_{j}') for j in jn[ControlType.TORQUE]], device=dev)
+        self.maps['ctrl']['springref'] = {j: int(m.jnt_qposadr[m.joint_names.index(j)]) for j in m.hinge_joint_names()}
+
+    # ---- per step -----------------------------------------------------------------------------------
+    def update_sensors(self, physics, links_only=False):
+        index = self.iteration % self.buffer_size
+        physics2data(physics=physics, iteration=index, data=self.data, maps=self.maps, units=self.units,
+                     links_only=links_only)
+
+    def before_step(self, action, physics):
+        """Operations before physics step (reference task.py:168-186)."""
+        assert self.iteration < self.n_iterations
+        full_step = not self.sim_iteration % self.substeps
+        if full_step or self.substeps_links:
+            self.update_sensors(physics=physics, links_only=not full_step)
+        for callback in self._callbacks:
+            if full_step or callback.substep:
+                callback.before_step(task=self, action=action, physics=physics)
+        if full_step and self._controller is not None:
+            self.step_control(physics)
+
+    def step_control(self, physics):
+        """Step control (reference task.py:288-346): ctrl[pos idx] = positions, ctrl[trq idx] =
+        torques*units.torques, qpos_spring[j] = springref."""
+        current_time = self.iteration*self.timestep
+        index = self.iteration % self.buffer_size
+        c = self._controller
+        c.step(iteration=index, time=current_time, timestep=self.timestep)
+        if c.joints_names[ControlType.POSITION]:
+            physics.data.ctrl[:, self.maps['ctrl']['pos']] = c.positions(iteration=index, time=current_time, timestep=self.timestep)
+        if c.joints_names[ControlType.TORQUE]:
+            physics.data.ctrl[:, self.maps['ctrl']['trq']] = c.torques(iteration=index, time=current_time, timestep=self.timestep)*self.units.torques
+            springrefs = c.springrefs(iteration=index, time=current_time, timestep=self.timestep)
+            if springrefs:
+                for joint, value in springrefs.items():
+                    physics.data.qpos_spring[:, self.maps['ctrl']['springref'][joint]] = value
+
+    def after_step(self, physics):
+        """Operations after physics step (reference task.py:348-369, including its sub-step counter quirk)."""
+        self.sim_iteration += 1
+        fullstep = not (self.sim_iteration + 1) % self.substeps
+        if fullstep:
+            self.iteration += 1
+        assert self.iteration <= self.n_iterations
+        if fullstep:
+            for callback in self._callbacks:
+                callback.after_step(task=self, physics=physics)
+
+    def get_reward(self, physics):
+        reward = 0
+        for callback in self._callbacks:
+            r = callback.get_reward(task=self, physics=physics)
+            if r is not None:
+                reward += r
+        return reward
+
+    def get_termination(self, physics):
+        terminate = None
+        for callback in self._callbacks:
+            if callback.get_termination(task=self, physics=physics):
+                terminate = 1
+        if self.iteration >= self.n_iterations:
+            terminate = 1
+        return terminate
+
+    # ---- fused fast path ------------------------------------------------------------------------------
+    def fusable(self):
+        """True when every per-step hook has a device implementation, so the whole before_step + mj_step
+        sequence can run inside one launch (fmj_step_fused)."""
+        cbs_ok = all(getattr(cb, 'fusable', False) for cb in self._callbacks)
+        ctl_ok = self._controller is None or getattr(self._controller, 'fusable', False)
+        return cbs_ok and ctl_ok and self.substeps == 1

@@ -1,0 +1,101 @@
+"""Drag forces — HIP counterpart of reference farms_mujoco/swimming/drag.pyx.
+
+Same class and method names; ``SwimmingHandler.step`` launches the HIP drag operator for every
+environment (C-ABI ``fmj_drag``) instead of looping over links in Cython (drag.pyx:389-411).
+"""
+import ctypes
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+
+class WaterProperties:
+    """Water properties (reference drag.pyx:271-306)."""
+
+    def __init__(self, surface, density, velocity, viscosity):
+        self._surface = float(surface)
+        self._density = float(density)
+        self._velocity = np.array(velocity, dtype=float)
+        self._viscosity = float(viscosity)
+
+    def surface(self, x=0.0, y=0.0): return self._surface
+    def density(self, x=0.0, y=0.0, z=0.0): return self._density
+    def velocity(self, x=0.0, y=0.0, z=0.0): return self._velocity
+    def viscosity(self, x=0.0, y=0.0, z=0.0): return self._viscosity
+
+    def set_velocity(self, vx, vy, vz):
+        self._velocity[:] = (vx, vy, vz)
+
+    def as_c(self, gravity=-9.81, use_buoyancy=True):
+        w = _lib.CWater()
+        w.surface, w.density, w.viscosity = self._surface, self._density, self._viscosity
+        w.velocity = (ctypes.c_float*3)(*self._velocity)
+        w.gravity = gravity          # hard-coded -9.81 at reference drag.pyx:409
+        w.use_buoyancy = int(use_buoyancy)
+        return w
+
+
+class SwimmingHandler:
+    """Swimming handler (reference drag.pyx:309-419)."""
+
+    def __init__(self, data, animat_options, arena_options, units, physics):
+        self.animat_options = animat_options
+        self.links = data.sensors.links
+        self.xfrc = data.sensors.xfrc
+        water_options = arena_options.water
+        self.drag = bool(water_options.drag)
+        self.sph = getattr(water_options, 'sph', False)
+        self.buoyancy = bool(water_options.buoyancy)
+        self.units = units
+        self.water = WaterProperties(surface=float(water_options.height), density=float(water_options.density),
+                                     velocity=np.array(water_options.velocity, dtype=float),
+                                     viscosity=float(water_options.viscosity))
+        links = [link for link in animat_options.morphology.links if link.swimming]
+        self.n_links = len(links)
+        m = physics.model
+        body_of = {n: i for i, n in enumerate(m.body_names)}
+        self.body_index = np.array([body_of[l.name] for l in links], np.int32)
+        self.masses = np.array([m.body_mass[b] for b in self.body_index], float)/units.kilograms   # drag.pyx:360-363
+        self.heights = np.array([l.height for l in links], float)/units.meters                    # drag.pyx:364-372
+        self.densities = np.array([l.density for l in links], float)
+        self.xfrc_indices = np.array([self.xfrc.names.index(l.name) for l in links], np.int32)
+        self.links_indices = np.array([self.links.names.index(l.name) for l in links], np.int32)
+        self.links_coefficients = np.array([np.array(l.drag_coefficients) for l in links], float).reshape(-1, 2, 3)
+        if self.sph:
+            self.water._surface = 1e8                                                              # drag.pyx:386-387
+        self.physics = physics
+        physics.set_swimming(self.links_indices, self.xfrc_indices, self.body_index, self.links_coefficients,
+                             self.masses, self.heights, self.densities)
+
+    def swim_dict(self):
+        """Arrays in the layout the oracle wrapper takes (tests only)."""
+        return dict(links_index=self.links_indices, xfrc_index=self.xfrc_indices, body_index=self.body_index,
+                    coefficients=self.links_coefficients, masses=self.masses, heights=self.heights,
+                    densities=self.densities)
+
+    def step(self, iteration, write_xfrc_applied=True):
+        """Swimming step for every env: links row ``iteration`` -> xfrc row ``iteration`` (+ the
+        xfrc_applied glue the reference leaves to an external callback)."""
+        if not (self.drag or self.sph) or not self.drag:
+            return
+        phys = self.physics
+        rows = _lib.CRows()
+        rows.links = self.links.array[iteration].data_ptr()
+        rows.xfrc = self.xfrc.array[iteration].data_ptr()
+        water = self.water.as_c(use_buoyancy=self.buoyancy)
+        units = self.units.as_c()
+        xa = phys.data.xfrc_applied.data_ptr() if write_xfrc_applied else None
+        _lib.check(phys._lib.fmj_drag(phys._ctx, ctypes.byref(rows), ctypes.byref(water), ctypes.byref(units),
+                                      ctypes.c_void_p(xa), ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
+
+    def set_water_velocity(self, velocity):
+        self.water.set_velocity(vx=velocity[0], vy=velocity[1], vz=velocity[2])
+
+
+def drag_forces(iteration, data_links, links_index, data_xfrc, xfrc_index, coefficients, z3, z4, water,
+                mass, height, density, gravity, use_buoyancy):
+    """Signature-compatible free function (reference drag.pyx:152-167).  A single-link call has no
+    batched equivalent; use :meth:`SwimmingHandler.step`, which processes every link of every env."""
+    raise NotImplementedError('drag_forces(single link) is not exposed; use SwimmingHandler.step (fmj_drag)')

@@ -1,0 +1,182 @@
+"""GPU parity of the drag / readout operators and of the fused loop against the fp64 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _relerr(a, b):
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.abs(a - b).max()/max(np.abs(b).max(), 1e-12)
+
+
+def _make_sim(n_envs, n_iterations, buffer_size=None, units=None, water_kwargs=None, seed=0, env_offset=0):
+    import torch
+    from farms_mujoco_amd.model import salamander33, synthetic_batch
+    from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
+    from farms_mujoco_amd.control import WaveController
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    m = salamander33()
+    qpos, qvel, psi = synthetic_batch(m, n_envs, seed=seed, env_offset=env_offset)
+    opts = SimulationOptions(timestep=m.timestep, n_iterations=n_iterations, units=units or SimulationUnitScaling())
+    arena = ArenaOptions(water=WaterOptions(**(water_kwargs or {})))
+    animat = AnimatOptions.from_model(m)
+    ctl = WaveController(m, psi)
+    sim = Simulation.from_sdf(opts, animat, arena, model=m, n_envs=n_envs, controller=ctl,
+                              buffer_size=buffer_size or n_iterations)
+    sim.reset()
+    d = sim.physics.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32)
+    d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    return sim, m, psi
+
+
+def _oracle_initial_state(oracle, sim, m):
+    d = sim.physics.data
+    st = dict(qpos=d.qpos.cpu().numpy().astype(np.float64), qvel=d.qvel.cpu().numpy().astype(np.float64))
+    n = st['qpos'].shape[0]
+    xp, xq, xi, sd = [], [], [], []
+    for e in range(n):
+        o = oracle.forward_debug(m, st['qpos'][e], st['qvel'][e])
+        s = o['sensordata'].copy(); s[6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0   # actuation disabled at reset
+        xp.append(o['xpos']); xq.append(o['xquat']); xi.append(o['xipos']); sd.append(s)
+    st.update(xpos=np.array(xp), xquat=np.array(xq), xipos=np.array(xi), sensordata=np.array(sd))
+    return st
+
+
+def _swim_water(sim):
+    h = [cb for cb in sim.task._callbacks][0].handler
+    w = h.water
+    return h.swim_dict(), dict(surface=w._surface, velocity=w._velocity, viscosity=w._viscosity, gravity=-9.81,
+                               use_buoyancy=h.buoyancy)
+
+
+def test_reset_forward_matches_oracle(oracle):
+    sim, m, psi = _make_sim(8, 10)
+    st = _oracle_initial_state(oracle, sim, m)
+    d = sim.physics.data
+    for k in ('xpos', 'xquat', 'xipos', 'sensordata'):
+        assert _relerr(getattr(d, k).cpu().numpy(), st[k]) < 2e-6, k
+
+
+@pytest.mark.parametrize('water_kwargs', [dict(height=0.0), dict(height=-0.12, velocity=[0.05, -0.02, 0.01], viscosity=1.3)])
+def test_fused_loop_matches_oracle(oracle, water_kwargs):
+    """200 fused iterations (readout -> drag -> glue -> wave ctrl -> mj_step): ring-buffer rows and final state
+    vs the fp64 oracle.  The second case puts the surface through the animal (some links dry, partial
+    buoyancy) and adds a water current."""
+    import torch
+    n, T = 16, 200
+    sim, m, psi = _make_sim(n, T, water_kwargs=water_kwargs)
+    st = _oracle_initial_state(oracle, sim, m)
+    swim, water = _swim_water(sim)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    c = sim.task._controller
+    wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
+                env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency)
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=T, controller=1, wave=wave, n_threads=8)
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    sens = sim.task.data.sensors
+    errs = dict(qpos=_relerr(d.qpos.cpu().numpy(), ref['qpos']), qvel=_relerr(d.qvel.cpu().numpy(), ref['qvel']),
+                links=_relerr(sens.links.array.cpu().numpy(), ref['links']),
+                joints=_relerr(sens.joints.array.cpu().numpy(), ref['joints']),
+                xfrc=_relerr(sens.xfrc.array.cpu().numpy(), ref['xfrc']))
+    print(errs)
+    assert errs['qpos'] < 1e-4 and errs['links'] < 1e-4 and errs['joints'] < 1e-3 and errs['xfrc'] < 1e-3, errs
+    # rows of links above the surface are never written (drag.pyx:192-194)
+    dry = ref['links'][..., 2] > water['surface']
+    assert np.all(sens.xfrc.array.cpu().numpy()[dry] == 0.0)
+    if water['surface'] < 0:
+        assert dry.any() and (~dry).any()
+
+
+def test_fused_equals_unfused_operators(oracle):
+    """The fused launch and the operator-by-operator path (fmj_physics2data, fmj_drag, torch ctrl write,
+    fmj_step) agree; the only difference is sin() evaluated by torch vs in-kernel sinf."""
+    import torch
+    n, T = 8, 50
+    sim_f, m, _ = _make_sim(n, T)
+    sim_u, _, _ = _make_sim(n, T)
+    sim_f.run(fused=True)
+    sim_u.run(fused=False)
+    torch.cuda.synchronize()
+    assert sim_f.task.iteration == sim_u.task.iteration == T
+    for k in ('qpos', 'qvel', 'xpos', 'sensordata'):
+        a = getattr(sim_f.physics.data, k).cpu().numpy(); b = getattr(sim_u.physics.data, k).cpu().numpy()
+        assert _relerr(a, b) < 2e-5, (k, _relerr(a, b))
+    for k in ('links', 'joints', 'xfrc'):
+        a = getattr(sim_f.task.data.sensors, k).array.cpu().numpy(); b = getattr(sim_u.task.data.sensors, k).array.cpu().numpy()
+        assert _relerr(a, b) < 2e-4, (k, _relerr(a, b))
+
+
+def test_ring_buffer_wraps(oracle):
+    """buffer_size < n_iterations: row index = iteration % buffer_size (task.py:158); chunked fused launches."""
+    import torch
+    n, T, B = 4, 37, 8
+    sim, m, _ = _make_sim(n, T, buffer_size=B)
+    sim_full, _, _ = _make_sim(n, T, buffer_size=T)
+    sim.run(fused=True); sim_full.run(fused=True)
+    torch.cuda.synchronize()
+    a = sim.task.data.sensors.links.array.cpu().numpy(); b = sim_full.task.data.sensors.links.array.cpu().numpy()
+    for it in range(T - B, T):
+        assert np.array_equal(a[it % B], b[it])
+    assert torch.equal(sim.physics.data.qpos, sim_full.physics.data.qpos)
+
+
+def test_drag_operator_random_rows(oracle):
+    """fmj_drag on random link rows (arbitrary quaternions incl. com != urdf orientation, links above and
+    below the surface, partial submersion, water current) vs drag.pyx restated in the oracle."""
+    import torch, ctypes
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    units = SimulationUnitScaling(meters=2.0, seconds=0.5, kilograms=3.0)
+    sim, m, _ = _make_sim(32, 2, units=units, water_kwargs=dict(height=0.0, velocity=[0.1, 0.2, -0.05], viscosity=0.7))
+    h = sim.task._callbacks[0].handler
+    rng = np.random.default_rng(3)
+    L = sim.task.data.sensors.links.array
+    rows = rng.normal(size=tuple(L.shape[1:]))*0.3
+    for c0 in (3, 10):
+        q = rng.normal(size=rows.shape[:-1] + (4,)); rows[..., c0:c0+4] = q/np.linalg.norm(q, axis=-1, keepdims=True)
+    rows[..., 2] = rng.uniform(-0.05, 0.02, rows.shape[:-1])     # some above, some partially submerged
+    L[0] = torch.as_tensor(rows, dtype=torch.float32)
+    rows32 = L[0].cpu().numpy().astype(np.float64)
+    X = sim.task.data.sensors.xfrc.array
+    X[0] = 7.0                                                   # sentinel: dry links must keep it
+    sim.physics.data.xfrc_applied[:] = 5.0
+    h.step(0)
+    torch.cuda.synchronize()
+    swim, water = _swim_water(sim)
+    xref, xaref = oracle.drag(swim, water, rows32, np.full(tuple(X.shape[1:]), 7.0), m.nbody,
+                              units=(units.newtons, units.torques))
+    got = X[0].cpu().numpy()
+    assert np.abs(got - xref).max() < 2e-6*max(1.0, np.abs(xref).max())
+    dry = rows32[..., 2] > 0.0
+    assert dry.any() and np.all(got[dry] == 7.0)
+    xa = sim.physics.data.xfrc_applied.cpu().numpy()
+    assert np.abs(xa[:, 1:] - xaref[:, 1:]).max() < 2e-6*max(1.0, np.abs(xaref).max())
+    assert np.all(xa[:, 1:][dry] == 0.0)                         # glue zeroes rows of dry links
+
+
+def test_physics2data_operator_units(oracle):
+    """fmj_physics2data with non-unit scaling vs physics.py:449-524 restated in the oracle."""
+    import torch
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    from farms_mujoco_amd.simulation.physics import physics2data
+    units = SimulationUnitScaling(meters=2.0, seconds=0.5, kilograms=3.0)
+    sim, m, _ = _make_sim(8, 4, units=units)
+    phys = sim.physics
+    rng = np.random.default_rng(5)
+    d = phys.data
+    d.qvel[:] = torch.as_tensor(rng.normal(size=tuple(d.qvel.shape))*0.3, dtype=torch.float32)
+    d.ctrl[:] = torch.as_tensor(rng.normal(size=tuple(d.ctrl.shape))*0.05, dtype=torch.float32)
+    phys.step(3)
+    physics2data(phys, 1, sim.task.data, sim.task.maps, units)
+    torch.cuda.synchronize()
+    f64 = lambda t: t.cpu().numpy().astype(np.float64)
+    links, joints = oracle.physics2data(m, f64(d.qpos), f64(d.qvel), f64(d.xpos), f64(d.xquat), f64(d.xipos),
+                                        f64(d.sensordata), phys.links_body, phys.joints_jnt, units=units.as_array())
+    assert _relerr(sim.task.data.sensors.links.array[1].cpu().numpy(), links) < 1e-6
+    assert _relerr(sim.task.data.sensors.joints.array[1].cpu().numpy(), joints) < 1e-6
+    assert float(sim.task.data.sensors.links.array[0].abs().max()) == 0.0      # other ring rows untouched
