@@ -45,7 +45,7 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
 
 struct DevModel {
   int nbody, nv, nq, nu, njnt, nM, nMpad;
-  int max_bdepth;     // longest root->body chain (bodies, incl. self)
+  int max_bdepth;     // pointer-jumping rounds = ceil(log2(longest root->body chain))
   int max_subsize;    // largest subtree (bodies)
   int rs;             // row stride of Hrow (multiple of 4, >= max dof depth + 1)
   int root_free;      // 1 if body 1 carries a free joint
@@ -63,7 +63,7 @@ struct DevModel {
   const float4* j_pos_k;      // joint pos xyz, stiffness
   const int4* b_info;         // parent, jnt type (-1 none), qposadr, dofadr
   const int4* b_info2;        // depth (chain length-1), subtree size, link row (-1), swim slot (-1)
-  const uint8_t* b_anc;       // [nbody][anc_stride] root-first chain incl. self
+  const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
   // per dof [64]
   const int4* d_info;         // body, depth, subtree size (dofs), joint row (-1)
   const float4* d_prm;        // armature, damping, qposadr(as float bits), is_hinge_or_slide
@@ -200,6 +200,9 @@ __device__ __forceinline__ float wave_sum(float v) {
 __device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wave-uniform
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
 }
+// Hides a value from loop-invariant code motion: per-body model constants are re-read from the
+// (L1/L2-resident) tables inside every step instead of pinning ~40 VGPRs across the whole loop.
+__device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // LDS ordering between lanes of the one wave that forms the workgroup
 #define WSYNC() __syncthreads()
 
@@ -272,7 +275,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
-  int P1, P2, CI, CD, HR, RK, QP, QV, XV, VT, ANC, total;
+  int P1, P2, CI, CD, HR, RK, QP, QV, XV, VT, ANC, CY, total;
 };
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride) {
   LdsLayout L;
@@ -283,25 +286,63 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
   L.CD = o; o += nv * 8;              // cdof
   L.HR = o; o += nv * rs;             // depth-indexed rows of H, then L
-  L.RK = o; o += FMJ_MAXD;            // broadcast pivot row
+  L.RK = o; o += FMJ_MAXD;            // broadcast pivot row (sized for the largest instantiation)
   L.QP = o; o += r4(nq);
   L.QV = o; o += r4(nv);
   L.XV = o; o += r4(nv);
   L.VT = o; o += 8;
   L.ANC = o; o += r4(nb * anc_stride) / 4;
+  L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
   L.total = o;
   return L;
 }
 
-template <bool FUSED>
+// Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
+// forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
+// every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
+__device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const StepArgs& A, int env, int it, bool isb,
+                                                    int link_row, int swim_slot, v3 xpos, q4 xquat, v3 xipos, v3 linvel,
+                                                    v3 angvel, float* xf) {
+  const int index = it % A.buffer_size;
+  const v3 r_com = scl3(xipos, A.inv_meters), r_urdf = scl3(xpos, A.inv_meters);
+  const v3 r_lin = scl3(linvel, A.inv_velocity), r_ang = scl3(angvel, A.inv_angvel);
+  const fq r_q = {xquat.x, xquat.y, xquat.z, xquat.w};   // wxyz -> xyzw (physics.py:458)
+  if (A.do_readout && isb && link_row >= 0) {
+    float* row = A.links + ((size_t)index * A.row_stride_links + (size_t)env * M.n_links * FMJ_LINK_SIZE) + link_row * FMJ_LINK_SIZE;
+    *(float4*)(row + 0) = make_float4(r_com.x, r_com.y, r_com.z, r_q.x);
+    *(float4*)(row + 4) = make_float4(r_q.y, r_q.z, r_q.w, r_urdf.x);
+    *(float4*)(row + 8) = make_float4(r_urdf.y, r_urdf.z, r_q.x, r_q.y);
+    *(float4*)(row + 12) = make_float4(r_q.z, r_q.w, r_lin.x, r_lin.y);
+    *(float4*)(row + 16) = make_float4(r_lin.z, r_ang.x, r_ang.y, r_ang.z);
+  }
+  if (A.do_drag) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) xf[k] = 0.f;
+    if (isb && swim_slot >= 0) {
+      const float4 s0 = M.s_c0[swim_slot], s1 = M.s_c1[swim_slot], s2 = M.s_c2[swim_slot];
+      v3 fo, to;
+      if (drag_link(r_com, r_q, r_q, r_lin, r_ang, s0, s1, s2.x, A, &fo, &to)) {
+        float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
+        *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
+        *(float2*)(xr + 2) = make_float2(fo.z, to.x);
+        *(float2*)(xr + 4) = make_float2(to.y, to.z);
+        const v3 fw = fq_rot(fo, r_q), tw = fq_rot(to, r_q);
+        xf[0] = fw.x * A.newtons; xf[1] = fw.y * A.newtons; xf[2] = fw.z * A.newtons;
+        xf[3] = tw.x * A.torques; xf[4] = tw.y * A.torques; xf[5] = tw.z * A.torques;
+      }
+    }
+  }
+}
+
+template <bool FUSED, int MAXD>
 __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu, RS = M.rs;
   const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride);
-  float* T = lds + LL.P1;  float* F = T;       // aliased: T is dead once the chains are composed
-  float* V = lds + LL.P2;  float* BUF = V;     // aliased: V is dead once cvel/cacc are known
+  float* T = lds + LL.P1;  float* F = T;       // T (transforms) -> W (acceleration scan) -> F (body force)
+  float* V = lds + LL.P2;  float* BUF = V;     // V (velocity scan) -> BUF (I w, m v)
   float* CI = lds + LL.CI;
   float* CD = lds + LL.CD;
   float* HR = lds + LL.HR;
@@ -310,161 +351,154 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
   float* QV = lds + LL.QV;
   float* XV = lds + LL.XV;
   float* VT = lds + LL.VT;
-  const uint8_t* ANC = (const uint8_t*)(lds + LL.ANC);
+  const uint8_t* JMP = (const uint8_t*)(lds + LL.ANC);   // [nb][anc_stride]: ancestor at distance 2^r
+  float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
 
-  // ---- per-lane constants: lane = body role -----------------------------------------------------
   const bool isb = lane > 0 && lane < nb;
   const int bl = isb ? lane : 0;
-  const float4 c_pos_mass = M.b_pos_mass[bl];
-  const float4 c_quat = M.b_quat[bl];
-  const float4 c_ipos = M.b_ipos[bl];
-  const float4 c_iquat = M.b_iquat[bl];
-  const float4 c_inertia = M.b_inertia[bl];
-  const float4 c_axis_q0 = M.j_axis_q0[bl];
-  const float4 c_jpos_k = M.j_pos_k[bl];
-  const int4 c_info = M.b_info[bl];     // parent, jtype, qadr, dadr
-  const int4 c_info2 = M.b_info2[bl];   // depth, subsize, link row, swim slot
-  const int jtype = isb ? c_info.y : -1;
-  const int qadr = c_info.z, dadr = c_info.w;
-  const int bdepth = isb ? c_info2.x : -1;
-  const int bsub = isb ? c_info2.y : 0;
-  // lane = dof role
   const bool isd = lane < nv;
   const int dl = isd ? lane : 0;
-  const int4 d_info = M.d_info[dl];     // body, depth, subsize(dofs), joint row
-  const float4 d_prm = M.d_prm[dl];     // armature, damping, qposadr bits, hinge/slide flag
-  const int4 d_act = M.d_act[dl];       // first actuator, count, joint sensor slot
-  const int d_qadr = __float_as_int(d_prm.z);
-  const bool d_scalar = isd && d_prm.w != 0.f;   // hinge / slide dof (not part of a free joint)
-  const int ddepth = isd ? d_info.y : 0;
-  const int dsub = isd ? d_info.z : 0;
+  // dof-role constants that index loops stay resident (2 VGPRs); everything else is re-read per step
+  const int4 d_info0 = M.d_info[dl];
+  const int ddepth = isd ? d_info0.y : 0;
+  const int dsub = isd ? d_info0.z : 0;
 
-  // ---- load chains + state ------------------------------------------------------------------------
+  // ---- load tables + state -------------------------------------------------------------------------
   {
-    uint32_t* anc_w = (uint32_t*)(lds + LL.ANC);
+    uint32_t* jw = (uint32_t*)(lds + LL.ANC);
     const int nw = r4(nb * M.anc_stride) / 4;
-    for (int i = lane; i < nw; i += 64) anc_w[i] = ((const uint32_t*)M.b_anc)[i];
-    for (int i = lane; i < nv * RS; i += 64) HR[i] = 0.f;     // padding slots must stay finite (see L)
+    for (int i = lane; i < nw; i += 64) jw[i] = ((const uint32_t*)M.b_anc)[i];
+    for (int i = lane; i < nv * RS; i += 64) HR[i] = 0.f;
   }
-  const float* gq = A.qpos + (size_t)env * nq;
-  const float* gv = A.qvel + (size_t)env * nv;
-  for (int i = lane; i < nq; i += 64) QP[i] = gq[i];
-  for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
-  if (lane < 8) VT[lane] = 0.f;
-  Carry cy;
   {
-    const float* p = A.xpos + ((size_t)env * nb + bl) * 3; cy.xpos = mk3(p[0], p[1], p[2]);
-    const float* q = A.xquat + ((size_t)env * nb + bl) * 4; cy.xquat.w = q[0]; cy.xquat.x = q[1]; cy.xquat.y = q[2]; cy.xquat.z = q[3];
-    const float* ip = A.xipos + ((size_t)env * nb + bl) * 3; cy.xipos = mk3(ip[0], ip[1], ip[2]);
-    const float* sd = A.sensordata + (size_t)env * M.nsensordata + 6 * (isb ? bl - 1 : 0);
-    cy.linvel = mk3(sd[0], sd[1], sd[2]); cy.angvel = mk3(sd[3], sd[4], sd[5]);
+    const float* gq = A.qpos + (size_t)env * nq;
+    const float* gv = A.qvel + (size_t)env * nv;
+    for (int i = lane; i < nq; i += 64) QP[i] = gq[i];
+    for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
+    if (lane < 8) VT[lane] = 0.f;
   }
-  float cy_actsum = 0.f;   // carried motor torque (sum of the joint's actuatorfrc, physics.py:510-524)
-  if (FUSED && d_scalar) {
-    const float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
+  float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
+  float cy_actsum = 0.f;                            // carried motor torque (physics.py:510-524)
+  if (FUSED) {
+    if (lane < nb) {
+      const float* p = A.xpos + (size_t)env * nb * 3 + lane * 3;
+      const float4 q = *(const float4*)(A.xquat + (size_t)env * nb * 4 + lane * 4);
+      const float* ip = A.xipos + (size_t)env * nb * 3 + lane * 3;
+      const float* sd = A.sensordata + (size_t)env * M.nsensordata + 6 * (isb ? lane - 1 : 0);
+      *(float4*)(CY + lane * 16) = make_float4(p[0], p[1], p[2], q.x);
+      *(float4*)(CY + lane * 16 + 4) = make_float4(q.y, q.z, q.w, ip[0]);
+      *(float4*)(CY + lane * 16 + 8) = make_float4(ip[1], ip[2], sd[0], sd[1]);
+      *(float4*)(CY + lane * 16 + 12) = make_float4(sd[2], sd[3], sd[4], sd[5]);
+    }
+    const float4 dp = M.d_prm[dl];
+    if (isd && dp.w != 0.f) {
+      const int4 da = M.d_act[dl];
+      const float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
 #pragma unroll
-    for (int a = 0; a < 4; a++) if (a < d_act.y) cy_actsum += sa[M.a_src[d_act.x + a]] * A.inv_torques;
+      for (int a = 0; a < 4; a++) if (a < da.y) cy_actsum += sa[M.a_src[da.x + a]] * A.inv_torques;
+    }
   }
-  float xfx = 0.f, xfy = 0.f, xfz = 0.f, xtx = 0.f, xty = 0.f, xtz = 0.f;   // world-frame external force on this body
   if (!(FUSED && A.do_drag) && A.xfrc_applied && isb) {
-    const float* xf = A.xfrc_applied + ((size_t)env * nb + bl) * 6;
-    xfx = xf[0]; xfy = xf[1]; xfz = xf[2]; xtx = xf[3]; xty = xf[4]; xtz = xf[5];
+    const float* x = A.xfrc_applied + (size_t)env * nb * 6 + bl * 6;
+#pragma unroll
+    for (int k = 0; k < 6; k++) xf[k] = x[k];
   }
   int warn = 0;
-  float my_qacc = 0.f, pre_q = 0.f, pre_qd = 0.f;
-  float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
   WSYNC();
 
+#pragma unroll 1
   for (int step = 0; step < A.n_steps; step++) {
     const int it = A.iteration0 + step;
+    const bool last = step == A.n_steps - 1;
+    const int blo = opaque(bl), dlo = opaque(dl);
     // ============ before_step (reference task.py:168-186) ============
-    if (FUSED) {
-      const int index = it % A.buffer_size;
-      v3 r_com = scl3(cy.xipos, A.inv_meters), r_urdf = scl3(cy.xpos, A.inv_meters);
-      v3 r_lin = scl3(cy.linvel, A.inv_velocity), r_ang = scl3(cy.angvel, A.inv_angvel);
-      fq r_q = {cy.xquat.x, cy.xquat.y, cy.xquat.z, cy.xquat.w};   // wxyz -> xyzw (physics.py:458)
-      if (A.do_readout && isb && c_info2.z >= 0) {   // physicslinks2data + physicslinksvelsensors2data
-        float* row = A.links + (size_t)index * A.row_stride_links + ((size_t)env * M.n_links + c_info2.z) * FMJ_LINK_SIZE;
-        *(float4*)(row + 0) = make_float4(r_com.x, r_com.y, r_com.z, r_q.x);
-        *(float4*)(row + 4) = make_float4(r_q.y, r_q.z, r_q.w, r_urdf.x);
-        *(float4*)(row + 8) = make_float4(r_urdf.y, r_urdf.z, r_q.x, r_q.y);
-        *(float4*)(row + 12) = make_float4(r_q.z, r_q.w, r_lin.x, r_lin.y);
-        *(float4*)(row + 16) = make_float4(r_lin.z, r_ang.x, r_ang.y, r_ang.z);
-      }
-      if (A.do_readout && d_scalar && d_info.w >= 0) {   // physicsjoints2data + actuators + limit force
-        float* row = A.joints + (size_t)index * A.row_stride_joints + ((size_t)env * M.n_joints + d_info.w) * FMJ_JOINT_SIZE;
-        row[FMJ_JOINT_POSITION] = QP[d_qadr];
+    if (FUSED) {      // links row + drag from the fields the last forward pass left (carried in LDS)
+      const int4 ci2 = M.b_info2[blo];
+      const int cl = lane < nb ? lane : 0;
+      const float4 c0 = *(const float4*)(CY + cl * 16), c1 = *(const float4*)(CY + cl * 16 + 4);
+      const float4 c2 = *(const float4*)(CY + cl * 16 + 8), c3 = *(const float4*)(CY + cl * 16 + 12);
+      const q4 cq = {c0.w, c1.x, c1.y, c1.z};
+      emit_links_and_drag(M, A, env, it, isb, ci2.z, ci2.w, mk3(c0.x, c0.y, c0.z), cq, mk3(c1.w, c2.x, c2.y),
+                          mk3(c2.z, c2.w, c3.x), mk3(c3.y, c3.z, c3.w), xf);
+    }
+    // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
+    if (FUSED && A.do_readout) {
+      const int4 di = M.d_info[dlo];
+      const float4 dp = M.d_prm[dlo];
+      if (isd && dp.w != 0.f && di.w >= 0) {
+        const int index = it % A.buffer_size;
+        float* row = A.joints + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
+        row[FMJ_JOINT_POSITION] = QP[__float_as_int(dp.z)];
         row[FMJ_JOINT_VELOCITY] = QV[lane] * A.inv_angvel;
         row[FMJ_JOINT_TORQUE] = cy_actsum;
         row[FMJ_JOINT_LIMIT_FORCE] = 0.f;
       }
-      if (A.do_drag) {                                   // SwimmingHandler.step + xfrc glue
-        xfx = xfy = xfz = xtx = xty = xtz = 0.f;
-        if (isb && c_info2.w >= 0) {
-          const float4 s0 = M.s_c0[c_info2.w], s1 = M.s_c1[c_info2.w], s2 = M.s_c2[c_info2.w];
-          v3 fo, to;
-          if (drag_link(r_com, r_q, r_q, r_lin, r_ang, s0, s1, s2.x, A, &fo, &to)) {
-            float* xr = A.xfrc + (size_t)index * A.row_stride_xfrc + ((size_t)env * M.n_xfrc + __float_as_int(s2.z)) * FMJ_XFRC_SIZE;
-            *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
-            *(float2*)(xr + 2) = make_float2(fo.z, to.x);
-            *(float2*)(xr + 4) = make_float2(to.y, to.z);
-            v3 fw = fq_rot(fo, r_q), tw = fq_rot(to, r_q);
-            xfx = fw.x * A.newtons; xfy = fw.y * A.newtons; xfz = fw.z * A.newtons;
-            xtx = tw.x * A.torques; xty = tw.y * A.torques; xtz = tw.z * A.torques;
-          }
-        }
-      }
     }
 
     // ============ mj_step ============
-    // ---- K: local transform, chain composition
-    if (lane < nb) {
-      v3 tp = mk3(c_pos_mass.x, c_pos_mass.y, c_pos_mass.z);
-      q4 tq = {c_quat.x, c_quat.y, c_quat.z, c_quat.w};
+    const int4 c_info = M.b_info[blo];        // parent, jtype, qadr, dadr
+    const int jtype = isb ? c_info.y : -1;
+    const int qadr = c_info.z, dadr = c_info.w;
+    const float4 c_axis_q0 = M.j_axis_q0[blo];
+    const float4 c_jpos_k = M.j_pos_k[blo];
+    // ---- K: local transforms, composed along the chains by pointer jumping (log2(depth) rounds)
+    v3 xp; q4 xq;
+    {
+      const float4 c_pos_mass = M.b_pos_mass[blo];
+      const float4 c_quat = M.b_quat[blo];
+      xp = mk3(c_pos_mass.x, c_pos_mass.y, c_pos_mass.z);
+      xq.w = c_quat.x; xq.x = c_quat.y; xq.y = c_quat.z; xq.z = c_quat.w;
       if (jtype == FMJ_JNT_FREE) {
-        tp = mk3(QP[qadr], QP[qadr + 1], QP[qadr + 2]);
+        xp = mk3(QP[qadr], QP[qadr + 1], QP[qadr + 2]);
         q4 rq = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
-        tq = qnormalize(rq);
+        xq = qnormalize(rq);
       } else if (jtype == FMJ_JNT_HINGE) {
         const float q = QP[qadr] - c_axis_q0.w;
-        v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), jp = mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z);
-        q4 ql = axisangle(ax, q);
-        v3 d = sub3(jp, qrot(ql, jp));
-        tp = add3(tp, qrot(tq, d));
-        tq = qmul(tq, ql);
+        const v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), jp = mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z);
+        const q4 ql = axisangle(ax, q);
+        xp = add3(xp, qrot(xq, sub3(jp, qrot(ql, jp))));
+        xq = qmul(xq, ql);
       } else if (jtype == FMJ_JNT_SLIDE) {
         const float q = QP[qadr] - c_axis_q0.w;
-        v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z);
-        tp = add3(tp, qrot(tq, scl3(ax, q)));
+        xp = add3(xp, qrot(xq, scl3(mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), q)));
       }
-      *(float4*)(T + lane * 8) = make_float4(tp.x, tp.y, tp.z, 0.f);
-      *(float4*)(T + lane * 8 + 4) = make_float4(tq.w, tq.x, tq.y, tq.z);
-    }
-    WSYNC();
-    v3 xp = mk3(0.f, 0.f, 0.f);
-    q4 xq = {1.f, 0.f, 0.f, 0.f};
-    for (int k = 0; k < M.max_bdepth; k++) {
-      if (k <= bdepth) {
-        const int a = ANC[lane * M.anc_stride + k];
-        float4 ap = *(const float4*)(T + a * 8), aq = *(const float4*)(T + a * 8 + 4);
-        xp = add3(xp, qrot(xq, mk3(ap.x, ap.y, ap.z)));
-        q4 aqq = {aq.x, aq.y, aq.z, aq.w};
-        xq = qmul(xq, aqq);
+      if (!isb) { xp = mk3(0.f, 0.f, 0.f); xq.w = 1.f; xq.x = xq.y = xq.z = 0.f; }
+      const uint32_t jm = lane < nb ? *(const uint32_t*)(JMP + lane * M.anc_stride) : 0u;   // rounds 0..3
+      for (int r = 0; r < M.max_bdepth; r++) {      // max_bdepth = number of jumping rounds
+        if (lane < nb) {
+          *(float4*)(T + lane * 8) = make_float4(xp.x, xp.y, xp.z, 0.f);
+          *(float4*)(T + lane * 8 + 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
+        }
+        WSYNC();
+        const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
+        const float4 ap = *(const float4*)(T + a * 8), aq = *(const float4*)(T + a * 8 + 4);
+        const q4 aqq = {aq.x, aq.y, aq.z, aq.w};
+        xp = add3(mk3(ap.x, ap.y, ap.z), qrot(aqq, xp));
+        xq = qmul(aqq, xq);
+        WSYNC();
       }
+      xq = qnormalize(xq);
     }
-    xq = qnormalize(xq);
     const m33 R = q2m(xq);
-    const v3 xi = add3(xp, mrot(R, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
-    // ---- C: subtree CoM of the (single) tree, cinert, cdof
-    const float mass = isb ? c_pos_mass.w : 0.f;
-    const v3 com = mk3(wave_sum(mass * xi.x) * M.mtot_inv, wave_sum(mass * xi.y) * M.mtot_inv, wave_sum(mass * xi.z) * M.mtot_inv);
+    v3 xi;
+    {
+      const float4 c_ipos = M.b_ipos[blo];
+      xi = add3(xp, mrot(R, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
+    }
+    // ---- C: tree CoM (wave reduction, result is wave-uniform), cinert, cdof
+    const float mass = isb ? M.b_pos_mass[blo].w : 0.f;
+    v3 com;
+    com.x = bcast(wave_sum(mass * xi.x), 0) * M.mtot_inv;
+    com.y = bcast(wave_sum(mass * xi.y), 0) * M.mtot_inv;
+    com.z = bcast(wave_sum(mass * xi.z), 0) * M.mtot_inv;
     float ci[10];
     {
+      const float4 c_iquat = M.b_iquat[blo];
+      const float4 c_inertia = M.b_inertia[blo];
       q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
       const m33 Ri = q2m(qmul(xq, iq));
       const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
-      // world-frame inertia about the body's own CoM
-      float iw[6];
+      float iw[6];     // world-frame inertia about the body's own CoM
       iw[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2;
       iw[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2;
       iw[2] = Ri.a[6] * Ri.a[6] * i0 + Ri.a[7] * Ri.a[7] * i1 + Ri.a[8] * Ri.a[8] * i2;
@@ -476,7 +510,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         for (int k = 0; k < 6; k++) iw[k] = 0.f;
       }
       // cinert about the tree CoM (MuJoCo's form) stays in registers for the RNE part
-      v3 d = sub3(xi, com);
+      const v3 d = sub3(xi, com);
       ci[0] = iw[0] + mass * (d.y * d.y + d.z * d.z);
       ci[1] = iw[1] + mass * (d.x * d.x + d.z * d.z);
       ci[2] = iw[2] + mass * (d.x * d.x + d.y * d.y);
@@ -485,78 +519,115 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       ci[5] = iw[5] - mass * d.y * d.z;
       ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
       if (lane < nb) {
-        // LDS gets the LOCAL description (inertia about the body's own CoM, CoM, mass): S assembles
-        // each composite inertia about its own subtree CoM, which avoids the m*d^2 inflation (and the
-        // fp32 cancellation it causes in M) of inertias taken about the distant tree CoM.
+        // LDS gets the LOCAL description (inertia about the body's own CoM, CoM, mass): S assembles each
+        // composite inertia about its own subtree CoM, avoiding the m*d^2 inflation (and the fp32
+        // cancellation it causes in M) of inertias taken about the distant tree CoM.
         *(float4*)(CI + lane * 12) = make_float4(iw[0], iw[1], iw[2], iw[3]);
         *(float4*)(CI + lane * 12 + 4) = make_float4(iw[4], iw[5], xi.x, xi.y);
         *(float2*)(CI + lane * 12 + 8) = make_float2(xi.z, mass);
       }
     }
-    s6 vJ = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
-    if (jtype == FMJ_JNT_HINGE || jtype == FMJ_JNT_SLIDE) {
-      v3 axw = mrot(R, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
-      s6 cd;
-      if (jtype == FMJ_JNT_HINGE) {
-        v3 anchor = add3(xp, mrot(R, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
-        cd.r = axw; cd.l = cross(axw, sub3(com, anchor));
-      } else { cd.r = mk3(0.f, 0.f, 0.f); cd.l = axw; }
-      lds_put6(CD + dadr * 8, cd);
-      vJ = s6scl(cd, QV[dadr]);
-    } else if (jtype == FMJ_JNT_FREE) {
-      v3 off = sub3(com, xp);
-      s6 vt = {mk3(0.f, 0.f, 0.f), mk3(QV[dadr], QV[dadr + 1], QV[dadr + 2])};
+    // ---- V: joint velocity vJ, then cvel = chain sum of vJ, cacc = a0 + chain sum of cvel_parent x vJ
+    s6 cv, ca;
+    {
+      s6 vJ = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+      s6 vt = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};       // translational part of a free root
+      if (jtype == FMJ_JNT_HINGE || jtype == FMJ_JNT_SLIDE) {
+        const v3 axw = mrot(R, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
+        s6 cd;
+        if (jtype == FMJ_JNT_HINGE) {
+          const v3 anchor = add3(xp, mrot(R, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
+          cd.r = axw; cd.l = cross(axw, sub3(com, anchor));
+        } else { cd.r = mk3(0.f, 0.f, 0.f); cd.l = axw; }
+        lds_put6(CD + dadr * 8, cd);
+        vJ = s6scl(cd, QV[dadr]);
+      } else if (jtype == FMJ_JNT_FREE) {
+        const v3 off = sub3(com, xp);
+        vt.l = mk3(QV[dadr], QV[dadr + 1], QV[dadr + 2]);
 #pragma unroll
-      for (int k = 0; k < 3; k++) {
-        s6 ct = {mk3(0.f, 0.f, 0.f), mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f)};
-        lds_put6(CD + (dadr + k) * 8, ct);
-        v3 col = mk3(R.a[k], R.a[k + 3], R.a[k + 6]);
-        s6 cr = {col, cross(col, off)};
-        lds_put6(CD + (dadr + 3 + k) * 8, cr);
-        vJ = s6add(vJ, s6scl(cr, QV[dadr + 3 + k]));
+        for (int k = 0; k < 3; k++) {
+          s6 ct = {mk3(0.f, 0.f, 0.f), mk3(k == 0 ? 1.f : 0.f, k == 1 ? 1.f : 0.f, k == 2 ? 1.f : 0.f)};
+          lds_put6(CD + (dadr + k) * 8, ct);
+          const v3 col = mk3(R.a[k], R.a[k + 3], R.a[k + 6]);
+          s6 cr = {col, cross(col, off)};
+          lds_put6(CD + (dadr + 3 + k) * 8, cr);
+          vJ = s6add(vJ, s6scl(cr, QV[dadr + 3 + k]));
+        }
       }
-      lds_put6(VT, vt);
-    }
-    if (lane < nb) lds_put6(V + lane * 8, vJ);
-    WSYNC();
-    // ---- V: chain walk for cvel / cacc
-    s6 cv = lds_get6(VT);
-    s6 ca = {mk3(0.f, 0.f, 0.f), mk3(-M.gx, -M.gy, -M.gz)};
-    for (int k = 0; k < M.max_bdepth; k++) {
-      if (k <= bdepth) {
-        const int a = ANC[lane * M.anc_stride + k];
-        s6 va = lds_get6(V + a * 8);
-        ca = s6add(ca, cross_motion(cv, va));
-        cv = s6add(cv, va);
+      const uint32_t jm = lane < nb ? *(const uint32_t*)(JMP + lane * M.anc_stride) : 0u;
+      cv = s6add(vJ, vt);
+      for (int r = 0; r < M.max_bdepth; r++) {
+        if (lane < nb) lds_put6(V + lane * 8, cv);
+        WSYNC();
+        const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
+        cv = s6add(cv, lds_get6(V + a * 8));
+        WSYNC();
       }
+      if (lane < nb) lds_put6(V + lane * 8, cv);
+      WSYNC();
+      // w = cdof_dot * qvel of this body's joint = cvel(before the joint's rotary part) x vJ
+      s6 cpar = lds_get6(V + (isb ? c_info.x : 0) * 8);
+      cpar = s6add(cpar, vt);
+      ca = cross_motion(cpar, vJ);
+      if (!isb) { ca.r = ca.l = mk3(0.f, 0.f, 0.f); }
+      for (int r = 0; r < M.max_bdepth; r++) {
+        if (lane < nb) lds_put6(T + lane * 8, ca);
+        WSYNC();
+        const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
+        ca = s6add(ca, lds_get6(T + a * 8));
+        WSYNC();
+      }
+      ca.l = sub3(ca.l, mk3(M.gx, M.gy, M.gz));
+      if (!isb) { cv.r = cv.l = mk3(0.f, 0.f, 0.f); }
     }
-    if (!isb) { cv.r = cv.l = mk3(0.f, 0.f, 0.f); }
     // ---- F: body force (inertial minus external), about the common point
     {
       s6 f = s6add(inert_mul(ci, ca), cross_force(cv, inert_mul(ci, cv)));
-      v3 fw = mk3(xfx, xfy, xfz), tw = mk3(xtx, xty, xtz);
+      const v3 fw = mk3(xf[0], xf[1], xf[2]), tw = mk3(xf[3], xf[4], xf[5]);
       f.r = sub3(f.r, add3(tw, cross(sub3(xi, com), fw)));
       f.l = sub3(f.l, fw);
       if (!isb) { f.r = f.l = mk3(0.f, 0.f, 0.f); }
-      if (lane < nb) lds_put6(F + lane * 8, f);     // T region: all chain reads completed before the last WSYNC
+      if (lane < nb) lds_put6(F + lane * 8, f);
+    }
+    // ---- sensors of this (pre-integration) state; they are next iteration's link data (mj_step lag)
+    {
+      const v3 linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
+      if (FUSED && lane < nb) {
+        *(float4*)(CY + lane * 16) = make_float4(xp.x, xp.y, xp.z, xq.w);
+        *(float4*)(CY + lane * 16 + 4) = make_float4(xq.x, xq.y, xq.z, xi.x);
+        *(float4*)(CY + lane * 16 + 8) = make_float4(xi.y, xi.z, linvel.x, linvel.y);
+        *(float4*)(CY + lane * 16 + 12) = make_float4(linvel.z, cv.r.x, cv.r.y, cv.r.z);
+      }
+      if (last && lane < nb) {
+        float* p = A.xpos + (size_t)env * nb * 3 + lane * 3; p[0] = xp.x; p[1] = xp.y; p[2] = xp.z;
+        *(float4*)(A.xquat + (size_t)env * nb * 4 + lane * 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
+        float* ip = A.xipos + (size_t)env * nb * 3 + lane * 3; ip[0] = xi.x; ip[1] = xi.y; ip[2] = xi.z;
+        if (isb) {
+          float* sp = A.sensordata + (size_t)env * M.nsensordata + 6 * (lane - 1);
+          *(float2*)(sp) = make_float2(linvel.x, linvel.y);
+          *(float2*)(sp + 2) = make_float2(linvel.z, cv.r.x);
+          *(float2*)(sp + 4) = make_float2(cv.r.y, cv.r.z);
+        }
+      }
     }
     WSYNC();
     // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize): accumulated force
-    // (about the tree CoM) and composite inertia taken about the body's own CoM, then shifted to
-    // the subtree CoM s (all lever arms are local to the subtree).
+    // (about the tree CoM) and composite inertia about the body's own CoM, shifted to the subtree CoM.
     {
+      const int bsub = isb ? M.b_info2[blo].y : 0;
       float cm = 0.f; v3 mr = mk3(0.f, 0.f, 0.f);
       float ic[6];
       s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
 #pragma unroll
       for (int k = 0; k < 6; k++) ic[k] = 0.f;
+#pragma unroll 1
       for (int k = 0; k < M.max_subsize; k++) {
         if (k < bsub) {
           const int d = lane + k;
-          float4 a = *(const float4*)(CI + d * 12), b = *(const float4*)(CI + d * 12 + 4);
-          float2 c = *(const float2*)(CI + d * 12 + 8);
+          const float4 a = *(const float4*)(CI + d * 12), b = *(const float4*)(CI + d * 12 + 4);
+          const float2 c = *(const float2*)(CI + d * 12 + 8);
           const float md = c.y;
-          v3 rr = sub3(mk3(b.z, b.w, c.x), xi);
+          const v3 rr = sub3(mk3(b.z, b.w, c.x), xi);
           cm += md; mr = add3(mr, scl3(rr, md));
           ic[0] += a.x + md * (rr.y * rr.y + rr.z * rr.z);
           ic[1] += a.y + md * (rr.x * rr.x + rr.z * rr.z);
@@ -568,10 +639,10 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         }
       }
       const float cminv = cm > 0.f ? 1.0f / cm : 0.f;
-      const v3 dl = scl3(mr, cminv);                 // subtree CoM relative to this body's CoM
-      const v3 sc = add3(xi, dl);
-      ic[0] -= cm * (dl.y * dl.y + dl.z * dl.z); ic[1] -= cm * (dl.x * dl.x + dl.z * dl.z); ic[2] -= cm * (dl.x * dl.x + dl.y * dl.y);
-      ic[3] += cm * dl.x * dl.y; ic[4] += cm * dl.x * dl.z; ic[5] += cm * dl.y * dl.z;
+      const v3 dlt = scl3(mr, cminv);                // subtree CoM relative to this body's CoM
+      const v3 sc = add3(xi, dlt);
+      ic[0] -= cm * (dlt.y * dlt.y + dlt.z * dlt.z); ic[1] -= cm * (dlt.x * dlt.x + dlt.z * dlt.z); ic[2] -= cm * (dlt.x * dlt.x + dlt.y * dlt.y);
+      ic[3] += cm * dlt.x * dlt.y; ic[4] += cm * dlt.x * dlt.z; ic[5] += cm * dlt.y * dlt.z;
       WSYNC();
       if (lane < nb) {
         *(float4*)(CI + lane * 12) = make_float4(ic[0], ic[1], ic[2], ic[3]);
@@ -583,17 +654,22 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     WSYNC();
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
+    float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
+    const float4 d_prm = M.d_prm[dlo];             // armature, damping, qposadr bits, hinge/slide flag
+    const int4 d_act = M.d_act[dlo];               // first actuator, count, joint sensor slot
+    const int d_qadr = __float_as_int(d_prm.z);
+    const bool d_scalar = isd && d_prm.w != 0.f;
     if (isd) {
-      const int body = d_info.x;
-      s6 cd = lds_get6(CD + lane * 8);
+      const int body = M.d_info[dlo].x;
+      const s6 cd = lds_get6(CD + lane * 8);
       {
-        float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
-        float2 c = *(const float2*)(CI + body * 12 + 8);
-        v3 vs = add3(cd.l, cross(cd.r, sub3(mk3(b.z, b.w, c.x), com)));   // velocity of the subtree CoM per unit dof rate
+        const float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
+        const float2 c = *(const float2*)(CI + body * 12 + 8);
+        const v3 vs = add3(cd.l, cross(cd.r, sub3(mk3(b.z, b.w, c.x), com)));   // velocity of the subtree CoM per unit dof rate
         s6 bf;
         bf.r = mk3(a.x * cd.r.x + a.w * cd.r.y + b.x * cd.r.z, a.w * cd.r.x + a.y * cd.r.y + b.y * cd.r.z, b.x * cd.r.x + b.y * cd.r.y + a.z * cd.r.z);
         bf.l = scl3(vs, c.y);
-        lds_put6(BUF + lane * 8, bf);   // V region: chain reads completed two WSYNCs ago
+        lds_put6(BUF + lane * 8, bf);
       }
       const float qd = QV[lane];
       qfrc = -d_prm.y * qd - s6dot(cd, lds_get6(F + body * 8));
@@ -629,10 +705,18 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         }
         qfrc += asum;
         cy_actsum = asum * A.inv_torques;
+        if (last) {
+          float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;   // actuatorfrc
+          if (0 < d_act.y) sa[M.a_src[d_act.x + 0]] = af0;
+          if (1 < d_act.y) sa[M.a_src[d_act.x + 1]] = af1;
+          if (2 < d_act.y) sa[M.a_src[d_act.x + 2]] = af2;
+          if (3 < d_act.y) sa[M.a_src[d_act.x + 3]] = af3;
+        }
       }
     }
     WSYNC();
     // ---- M: H entries, one per lane per round: M_ij = w_j . (I_s w_i) + v_j(s) . (m v_i(s)), s = subtree CoM of dof i's body
+#pragma unroll 1
     for (int e = lane; e < M.nMpad; e += 64) {
       const uint32_t t = M.m_tab[e];
       if (t >> 24) {
@@ -646,46 +730,49 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     }
     WSYNC();
     // ---- L: L'DL with register rows, pivot row k broadcast through LDS.
-    float r[FMJ_MAXD];
-#pragma unroll
-    for (int d = 0; d < FMJ_MAXD; d += 4) {
-      float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (d < RS && isd) t = *(const float4*)(HR + lane * RS + d);
-      // slots past the lane's own depth collect -t*rk garbage during elimination: never read as
-      // matrix entries, but they must not carry over from step to step (they would grow by 1/D each step)
-      r[d] = d <= ddepth ? t.x : 0.f; r[d + 1] = d + 1 <= ddepth ? t.y : 0.f;
-      r[d + 2] = d + 2 <= ddepth ? t.z : 0.f; r[d + 3] = d + 3 <= ddepth ? t.w : 0.f;
-    }
-    float dinv_mine = 0.f;
-    for (int k = nv - 1; k >= 0; k--) {
-      const int depk = __builtin_amdgcn_readlane(ddepth, k);
-      if (lane == k) {
-#pragma unroll
-        for (int d = 0; d < FMJ_MAXD; d += 4) if (d <= depk) *(float4*)(RK + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
-      }
-      WSYNC();
-      const float dk_inv = 1.0f / RK[depk];
-      const bool anc = lane < k && k < lane + dsub;
-      const float t = anc ? RK[ddepth] * dk_inv : 0.f;
-#pragma unroll
-      for (int d = 0; d < FMJ_MAXD; d += 4) {
-        if (d <= depk) {
-          float4 rk = *(const float4*)(RK + d);
-          r[d] = fmaf(-t, rk.x, r[d]); r[d + 1] = fmaf(-t, rk.y, r[d + 1]);
-          r[d + 2] = fmaf(-t, rk.z, r[d + 2]); r[d + 3] = fmaf(-t, rk.w, r[d + 3]);
-        }
-      }
-      if (lane == k) {
-        dinv_mine = dk_inv;
-#pragma unroll
-        for (int d = 0; d < FMJ_MAXD; d += 4) if (d <= depk)
-          *(float4*)(HR + lane * RS + d) = make_float4(r[d] * dk_inv, r[d + 1] * dk_inv, r[d + 2] * dk_inv, r[d + 3] * dk_inv);
-      }
-      WSYNC();
-    }
-    // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts
+    float my_qacc;
     {
+      float r[MAXD];
+#pragma unroll
+      for (int d = 0; d < MAXD; d += 4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (d < RS && isd) t = *(const float4*)(HR + lane * RS + d);
+        // slots past the lane's own depth collect -t*rk garbage during elimination: never read as
+        // matrix entries, but they must not carry over from step to step (they would grow by 1/D each step)
+        r[d] = d <= ddepth ? t.x : 0.f; r[d + 1] = d + 1 <= ddepth ? t.y : 0.f;
+        r[d + 2] = d + 2 <= ddepth ? t.z : 0.f; r[d + 3] = d + 3 <= ddepth ? t.w : 0.f;
+      }
+      float dinv_mine = 0.f;
+#pragma unroll 1
+      for (int k = nv - 1; k >= 0; k--) {
+        const int depk = __builtin_amdgcn_readlane(ddepth, k);
+        if (lane == k) {
+#pragma unroll
+          for (int d = 0; d < MAXD; d += 4) if (d <= depk) *(float4*)(RK + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
+        }
+        WSYNC();
+        const float dk_inv = 1.0f / RK[depk];
+        const bool anc = lane < k && k < lane + dsub;
+        const float t = anc ? RK[ddepth] * dk_inv : 0.f;
+#pragma unroll
+        for (int d = 0; d < MAXD; d += 4) {
+          if (d <= depk) {
+            const float4 rk = *(const float4*)(RK + d);
+            r[d] = fmaf(-t, rk.x, r[d]); r[d + 1] = fmaf(-t, rk.y, r[d + 1]);
+            r[d + 2] = fmaf(-t, rk.z, r[d + 2]); r[d + 3] = fmaf(-t, rk.w, r[d + 3]);
+          }
+        }
+        if (lane == k) {
+          dinv_mine = dk_inv;
+#pragma unroll
+          for (int d = 0; d < MAXD; d += 4) if (d <= depk)
+            *(float4*)(HR + lane * RS + d) = make_float4(r[d] * dk_inv, r[d + 1] * dk_inv, r[d + 2] * dk_inv, r[d + 3] * dk_inv);
+        }
+        WSYNC();
+      }
+      // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts
       float x = qfrc;
+#pragma unroll 1
       for (int i = nv - 1; i >= 1; i--) {
         const float xi_ = bcast(x, i);
         const bool anc = lane < i && i < lane + dsub;
@@ -693,6 +780,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         x = fmaf(-l, xi_, x);
       }
       x *= dinv_mine;
+#pragma unroll 1
       for (int j = 0; j < nv - 1; j++) {
         const float xj = bcast(x, j);
         const int depj = __builtin_amdgcn_readlane(ddepth, j);
@@ -703,64 +791,44 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
       my_qacc = x;
     }
-    // ---- sensors of the pre-integration state (mj_forward), then semi-implicit Euler
-    cy.xpos = xp; cy.xquat = xq; cy.xipos = xi;
-    cy.angvel = cv.r;
-    cy.linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
+    // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
     const float hstep = A.integrate ? M.h : 0.f;     // fmj_forward: mj_forward only
     if (isd) {
       if (!(fabsf(my_qacc) <= 1e10f)) warn |= FMJ_WARN_BADQACC;
       XV[lane] = my_qacc;
-      pre_qd = QV[lane];
+      const float pre_qd = QV[lane];
       const float nvel = pre_qd + hstep * my_qacc;
       QV[lane] = nvel;
-      if (d_scalar) { pre_q = QP[d_qadr]; QP[d_qadr] = pre_q + hstep * nvel; }
+      if (d_scalar) {
+        const float pre_q = QP[d_qadr];
+        QP[d_qadr] = pre_q + hstep * nvel;
+        if (last) {
+          float* s = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z;   // jointpos, jointvel, jointlimitfrc
+          s[0] = pre_q; s[1] = pre_qd; s[2] = 0.f;
+        }
+      }
       if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
     }
     WSYNC();
     if (jtype == FMJ_JNT_FREE && A.integrate) {     // free joint position update (lane = root body)
       QP[qadr] += M.h * QV[dadr]; QP[qadr + 1] += M.h * QV[dadr + 1]; QP[qadr + 2] += M.h * QV[dadr + 2];
-      v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
-      float n = sqrtf(dot3(w, w));
+      const v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
+      const float n = sqrtf(dot3(w, w));
       q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
       qo = qnormalize(qo);
-      if (n >= 1e-15f) {
-        q4 qr = axisangle(scl3(w, 1.0f / n), M.h * n);
-        qo = qmul(qo, qr);
-      }
+      if (n >= 1e-15f) qo = qmul(qo, axisangle(scl3(w, 1.0f / n), M.h * n));
       QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
       if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
     }
     WSYNC();
   }
 
-  // ---- store state + derived fields --------------------------------------------------------------
+  // ---- store state ---------------------------------------------------------------------------------------
   float* oq = A.qpos + (size_t)env * nq;
   float* ov = A.qvel + (size_t)env * nv;
   for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
   for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
   if (A.qacc) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
-  if (lane < nb) {
-    float* p = A.xpos + ((size_t)env * nb + lane) * 3; p[0] = cy.xpos.x; p[1] = cy.xpos.y; p[2] = cy.xpos.z;
-    *(float4*)(A.xquat + ((size_t)env * nb + lane) * 4) = make_float4(cy.xquat.w, cy.xquat.x, cy.xquat.y, cy.xquat.z);
-    float* ip = A.xipos + ((size_t)env * nb + lane) * 3; ip[0] = cy.xipos.x; ip[1] = cy.xipos.y; ip[2] = cy.xipos.z;
-  }
-  float* sd = A.sensordata + (size_t)env * M.nsensordata;
-  if (isb) {
-    float* s = sd + 6 * (lane - 1);
-    *(float2*)(s) = make_float2(cy.linvel.x, cy.linvel.y);
-    *(float2*)(s + 2) = make_float2(cy.linvel.z, cy.angvel.x);
-    *(float2*)(s + 4) = make_float2(cy.angvel.y, cy.angvel.z);
-  }
-  if (d_scalar && A.n_steps > 0) {
-    float* s = sd + 6 * (nb - 1) + 3 * d_act.z;            // jointpos, jointvel, jointlimitfrc
-    s[0] = pre_q; s[1] = pre_qd; s[2] = 0.f;
-    float* sa = sd + 6 * (nb - 1) + 3 * M.njs;            // actuatorfrc
-    if (0 < d_act.y) sa[M.a_src[d_act.x + 0]] = af0;
-    if (1 < d_act.y) sa[M.a_src[d_act.x + 1]] = af1;
-    if (2 < d_act.y) sa[M.a_src[d_act.x + 2]] = af2;
-    if (3 < d_act.y) sa[M.a_src[d_act.x + 3]] = af3;
-  }
   if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * A.n_steps;
   if (__ballot(warn != 0)) {
     int w = warn;
@@ -858,6 +926,28 @@ static int upload(fmj_ctx* c, const std::vector<T>& h, const T** dptr) {
 static float4 f4(double a, double b, double c, double d) { return make_float4((float)a, (float)b, (float)c, (float)d); }
 static float ibits(int i) { float f; memcpy(&f, &i, 4); return f; }
 
+// pick the instantiation whose register row length matches the model's dof-chain length
+typedef void (*step_kernel_t)(const DevModel, const StepArgs);
+template <bool FUSED>
+static step_kernel_t pick_step_kernel(int rs) {
+  switch (rs) {
+    case 4: case 8: return fmj_step_kernel<FUSED, 8>;
+    case 12: return fmj_step_kernel<FUSED, 12>;
+    case 16: return fmj_step_kernel<FUSED, 16>;
+    case 20: return fmj_step_kernel<FUSED, 20>;
+    case 24: return fmj_step_kernel<FUSED, 24>;
+    case 28: return fmj_step_kernel<FUSED, 28>;
+    default: return fmj_step_kernel<FUSED, 32>;
+  }
+}
+static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
+  step_kernel_t k = fused ? pick_step_kernel<true>(c->dm.rs) : pick_step_kernel<false>(c->dm.rs);
+  hipLaunchKernelGGL(k, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
+  return FMJ_OK;
+}
+
 extern "C" {
 
 const char* fmj_last_error(void) { return g_err.c_str(); }
@@ -934,13 +1024,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   DevModel& D = c->dm;
   memset(&D, 0, sizeof D);
   D.nbody = nb; D.nv = nv; D.nq = nq; D.nu = nu; D.njnt = nj; D.nM = m->nM;
-  D.max_bdepth = max_bdepth; D.max_subsize = max_sub;
+  { int rounds = 0; while ((1 << rounds) < max_bdepth) rounds++; D.max_bdepth = rounds; }   // pointer-jumping rounds
+  D.max_subsize = max_sub;
   D.rs = r4(max_ddepth + 1);
   D.root_free = m->body_jntadr[1] >= 0 && m->jnt_type[m->body_jntadr[1]] == FMJ_JNT_FREE;
   D.h = (float)m->timestep; D.gx = (float)m->gravity[0]; D.gy = (float)m->gravity[1]; D.gz = (float)m->gravity[2];
   double mtot = 0; for (int i = 1; i < nb; i++) mtot += m->body_mass[i];
   D.mtot_inv = (float)(1.0 / mtot);
-  D.anc_stride = r4(max_bdepth);
+  D.anc_stride = r4(D.max_bdepth > 4 ? D.max_bdepth : 4);
   int njs = 0; for (int j = 0; j < nj; j++) njs += m->jnt_type[j] != FMJ_JNT_FREE;
   D.njs = njs; D.nsensordata = 6 * (nb - 1) + 3 * njs + nu;
   c->layout.nsensordata = D.nsensordata; c->layout.framelinvel_adr = 0; c->layout.jointpos_adr = 6 * (nb - 1);
@@ -976,8 +1067,13 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     } else b_info[i] = make_int4(m->body_parentid[i], -1, 0, 0);
     c->body_link_row[i] = i - 1;
     b_info2[i] = make_int4(bdepth[i], subsize[i], i - 1, -1);
-    int k = bdepth[i];
-    for (int a = i; a >= 1; a = m->body_parentid[a]) b_anc[(size_t)i * D.anc_stride + k--] = (uint8_t)a;
+    {   // pointer-jumping table: ancestor at distance 2^r (0 = world, which holds the identity)
+      for (int r = 0; r < D.max_bdepth; r++) {
+        int a = i, hops = 1 << r;
+        while (hops-- > 0 && a > 0) a = m->body_parentid[a];
+        b_anc[(size_t)i * D.anc_stride + r] = (uint8_t)a;
+      }
+    }
   }
   D.any_stiffness = any_k;
   D.n_links = nb - 1; D.n_joints = njs; D.n_xfrc = nb - 1; D.ns = 0;
@@ -1031,8 +1127,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride);
   c->lds_bytes = (size_t)L.total * sizeof(float);
   if (c->lds_bytes > 64 * 1024) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)fmj_step_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-    hipError_t e2 = hipFuncSetAttribute((const void*)fmj_step_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    hipError_t e1 = hipFuncSetAttribute((const void*)pick_step_kernel<true>(D.rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)pick_step_kernel<false>(D.rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) { fmj_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_create: LDS request too large"); }
   }
   *out = c;
@@ -1130,9 +1226,7 @@ int fmj_step(fmj_ctx* c, const fmj_data* d, int32_t n_steps, int64_t ctrl_step_s
   if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step: qpos_spring required (model has joint stiffness)");
   A.n_steps = n_steps; A.ctrl_step_stride = ctrl_step_stride; A.integrate = 1;
   HIP_TRY(hipSetDevice(c->device));
-  hipLaunchKernelGGL(fmj_step_kernel<false>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
-  HIP_TRY(hipGetLastError());
-  return FMJ_OK;
+  return launch_step(c, false, A, stream);
 }
 
 int fmj_forward(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, void* stream) {
@@ -1141,9 +1235,7 @@ int fmj_forward(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, void* 
   if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_forward: qpos_spring required (model has joint stiffness)");
   A.n_steps = 1; A.integrate = 0; A.disable_actuation = disable_actuation;
   HIP_TRY(hipSetDevice(c->device));
-  hipLaunchKernelGGL(fmj_step_kernel<false>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
-  HIP_TRY(hipGetLastError());
-  return FMJ_OK;
+  return launch_step(c, false, A, stream);
 }
 
 int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void* stream) {
@@ -1163,9 +1255,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
   HIP_TRY(hipSetDevice(c->device));
-  hipLaunchKernelGGL(fmj_step_kernel<true>, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
-  HIP_TRY(hipGetLastError());
-  return FMJ_OK;
+  return launch_step(c, true, A, stream);
 }
 
 int fmj_drag(fmj_ctx* c, const fmj_rows* rows, const fmj_water* water, const fmj_units* units, float* xfrc_applied, void* stream) {

@@ -106,10 +106,10 @@ def test_fused_equals_unfused_operators(oracle):
     assert sim_f.task.iteration == sim_u.task.iteration == T
     for k in ('qpos', 'qvel', 'xpos', 'sensordata'):
         a = getattr(sim_f.physics.data, k).cpu().numpy(); b = getattr(sim_u.physics.data, k).cpu().numpy()
-        assert _relerr(a, b) < 2e-5, (k, _relerr(a, b))
+        assert _relerr(a, b) < 5e-4, (k, _relerr(a, b))
     for k in ('links', 'joints', 'xfrc'):
         a = getattr(sim_f.task.data.sensors, k).array.cpu().numpy(); b = getattr(sim_u.task.data.sensors, k).array.cpu().numpy()
-        assert _relerr(a, b) < 2e-4, (k, _relerr(a, b))
+        assert _relerr(a, b) < 5e-4, (k, _relerr(a, b))
 
 
 def test_ring_buffer_wraps(oracle):
