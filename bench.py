@@ -54,13 +54,15 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device):
     return sim, m, (qpos, qvel, psi)
 
 
-def cpu_baseline(m, sim, n_envs=256, n_steps=200):
+def cpu_baseline(m, sim, target_seconds=15.0):
     """The fp64 CPU oracle (C restatement, NOT MuJoCo: the reference's mj_step loop cannot run here, see
     BASELINE.md §2) timed on this box's host cores on a bounded sample of the same workload."""
     import subprocess
     from oracle import oracle
     from farms_mujoco_amd.model import synthetic_batch
-    cores = os.cpu_count() or 1
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    cores = min(cores, 16) if os.environ.get('GRAFT_REPO_ROOT') else cores     # a 1-GPU box grants a 16-core share
+    n_envs = 64*cores                                                          # >= 64 envs per thread
     so = os.path.join(ROOT, 'oracle', '_build', 'libfmj_oracle_native.so')
     try:
         subprocess.check_call(['make', '-C', os.path.join(ROOT, 'oracle'), '-s', 'native'])
@@ -80,7 +82,10 @@ def cpu_baseline(m, sim, n_envs=256, n_steps=200):
     wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(), env_phase=psi, frequency=c.frequency)
     water = dict(surface=h.water._surface, velocity=h.water._velocity, viscosity=h.water._viscosity, gravity=-9.81,
                  use_buoyancy=h.buoyancy)
-    oracle.run_fused(m, st, 2, swim=h.swim_dict(), water=water, buffer_size=2, controller=1, wave=wave, n_threads=cores)
+    t0 = time.perf_counter()
+    oracle.run_fused(m, st, 20, swim=h.swim_dict(), water=water, buffer_size=20, controller=1, wave=wave, n_threads=cores)
+    rate = n_envs*20/(time.perf_counter() - t0)                                # calibration pass
+    n_steps = int(max(50, min(5000, target_seconds*rate/n_envs)))
     t0 = time.perf_counter()
     oracle.run_fused(m, st, n_steps, swim=h.swim_dict(), water=water, buffer_size=n_steps, controller=1, wave=wave,
                      n_threads=cores)
@@ -143,10 +148,8 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    from farms_mujoco_amd.sharding import max_over_ranks
+    dt = max_over_ranks(dt, device=device)
     sim.physics.check_invalid_state()
 
     if rank == 0:

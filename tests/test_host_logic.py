@@ -1,0 +1,93 @@
+"""ExperimentTask / Simulation sequencing logic (no GPU): iteration counters, ring index, sub-step quirk,
+kwargs strictness — mirrored from reference farms_mujoco/simulation/task.py."""
+import numpy as np
+import pytest
+
+from farms_mujoco_amd.simulation.task import ExperimentTask, TaskCallback, duration2nit
+
+
+class _FakePhysics:
+    pass
+
+
+class _Recorder(TaskCallback):
+    def __init__(self, substep=False):
+        super().__init__(substep=substep)
+        self.before, self.after = [], []
+
+    def before_step(self, task, action, physics): self.before.append((task.sim_iteration, task.iteration))
+    def after_step(self, task, physics): self.after.append((task.sim_iteration, task.iteration))
+
+
+def _task(**kw):
+    t = ExperimentTask(base_link='b', n_iterations=kw.pop('n_iterations', 6), timestep=1e-3, **kw)
+    t.update_sensors = lambda physics, links_only=False: t._sensor_calls.append((t.iteration % t.buffer_size, links_only))
+    t._sensor_calls = []
+    return t
+
+
+def test_kwargs_strictness():
+    with pytest.raises(AssertionError):
+        ExperimentTask(base_link='b', n_iterations=1, timestep=1e-3, bogus=1)      # task.py:73
+    assert duration2nit(1.0, 1e-3) == 1000
+
+
+def test_counters_no_substeps():
+    cb = _Recorder()
+    t = _task(callbacks=[cb], buffer_size=4)
+    for _ in range(6):
+        t.before_step(None, _FakePhysics()); t.after_step(_FakePhysics())
+    assert t.iteration == 6 and t.sim_iteration == 6
+    assert [c[0] for c in t._sensor_calls] == [0, 1, 2, 3, 0, 1]          # ring index = iteration % buffer_size
+    assert all(not lo for _, lo in t._sensor_calls)
+    assert cb.before == [(i, i) for i in range(6)]
+    assert t.get_termination(_FakePhysics()) == 1
+
+
+def test_substep_quirk_matches_reference():
+    """With substeps > 1 the reference advances `iteration` after the first sub-step of each group
+    (task.py:352-355 tests (sim_iteration + 1) % substeps after incrementing)."""
+    sub = 3
+    cb, cbs = _Recorder(), _Recorder(substep=True)
+    t = _task(n_iterations=4, substeps=sub, callbacks=[cb, cbs])
+    its = []
+    for _ in range(4*sub - 1):
+        t.before_step(None, _FakePhysics()); t.after_step(_FakePhysics())
+        its.append(t.iteration)
+    assert its[:7] == [0, 1, 1, 1, 2, 2, 2]
+    # full-step callback only on sim_iteration % substeps == 0, sub-step callback every step
+    assert [s for s, _ in cb.before] == [0, 3, 6, 9]
+    assert len(cbs.before) == 4*sub - 1
+    # sensors: full rows on full steps, links_only rows on sub-steps because a callback asked for sub-steps
+    assert [lo for _, lo in t._sensor_calls[:4]] == [False, True, True, False]
+
+
+def test_fusable_rules():
+    class DevCb(TaskCallback):
+        fusable = True
+    assert _task().fusable()
+    assert _task(callbacks=[DevCb()]).fusable()
+    assert not _task(callbacks=[_Recorder()]).fusable()        # arbitrary host callbacks need per-step launches
+    assert not _task(callbacks=[DevCb()], substeps=2).fusable()
+
+
+def test_units_and_options():
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    from farms_mujoco_amd.options import SimulationOptions, WaterOptions
+    u = SimulationUnitScaling(meters=2.0, seconds=0.5, kilograms=3.0)
+    assert u.velocity == 4.0 and u.acceleration == 8.0 and u.newtons == 24.0 and u.torques == 48.0
+    assert u.angular_velocity == 2.0 and u.inertia == 12.0
+    with pytest.raises(AssertionError):
+        SimulationOptions(nope=1)
+    with pytest.raises(AssertionError):
+        WaterOptions(nope=1)
+    assert SimulationOptions().integrator == 'Euler'
+
+
+def test_synthetic_batch_is_keyed_by_global_index():
+    """Env e's inputs depend only on its global index, so any contiguous sharding reproduces them."""
+    from farms_mujoco_amd.model import salamander33, synthetic_batch
+    m = salamander33()
+    q, v, psi = synthetic_batch(m, 12, seed=3)
+    q2, v2, psi2 = synthetic_batch(m, 5, seed=3, env_offset=4)
+    assert np.array_equal(q[4:9], q2) and np.array_equal(psi[4:9], psi2)
