@@ -334,12 +334,23 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
   }
 }
 
+// Diagnostic build only (-DFMJ_STAMPS): per-phase s_memtime deltas of env 0, summed over the steps of a launch,
+// written over qacc[0, :]. Never enabled in the shipped library; its numbers are shares, not run times.
+#ifdef FMJ_STAMPS
+#define NSTAMP 14
+#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
+    stamp_acc[i] += (float)(t_ - stamp_prev); stamp_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#else
+#define STAMP(i)
+#endif
+
 template <bool FUSED, int MAXD>
 __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
-  const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu, RS = M.rs;
+  const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
+  constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
   const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride);
   float* T = lds + LL.P1;  float* F = T;       // T (transforms) -> W (acceleration scan) -> F (body force)
   float* V = lds + LL.P2;  float* BUF = V;     // V (velocity scan) -> BUF (I w, m v)
@@ -368,7 +379,6 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     uint32_t* jw = (uint32_t*)(lds + LL.ANC);
     const int nw = r4(nb * M.anc_stride) / 4;
     for (int i = lane; i < nw; i += 64) jw[i] = ((const uint32_t*)M.b_anc)[i];
-    for (int i = lane; i < nv * RS; i += 64) HR[i] = 0.f;
   }
   {
     const float* gq = A.qpos + (size_t)env * nq;
@@ -405,9 +415,18 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
   }
   int warn = 0;
   WSYNC();
+#ifdef FMJ_STAMPS
+  float stamp_acc[NSTAMP];
+#pragma unroll
+  for (int i = 0; i < NSTAMP; i++) stamp_acc[i] = 0.f;
+  unsigned long long stamp_prev = __builtin_amdgcn_s_memtime();
+#endif
 
+  const int lane_outer = lane;
 #pragma unroll 1
   for (int step = 0; step < A.n_steps; step++) {
+    // per-lane LDS/global addresses are recomputed every step instead of being hoisted and spilled
+    const int lane = opaque(lane_outer);
     const int it = A.iteration0 + step;
     const bool last = step == A.n_steps - 1;
     const int blo = opaque(bl), dlo = opaque(dl);
@@ -421,6 +440,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       emit_links_and_drag(M, A, env, it, isb, ci2.z, ci2.w, mk3(c0.x, c0.y, c0.z), cq, mk3(c1.w, c2.x, c2.y),
                           mk3(c2.z, c2.w, c3.x), mk3(c3.y, c3.z, c3.w), xf);
     }
+    STAMP(0);   // emit links + drag
     // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
     if (FUSED && A.do_readout) {
       const int4 di = M.d_info[dlo];
@@ -435,6 +455,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
     }
 
+    STAMP(1);   // joints row
     // ============ mj_step ============
     const int4 c_info = M.b_info[blo];        // parent, jtype, qadr, dadr
     const int jtype = isb ? c_info.y : -1;
@@ -479,11 +500,11 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
       xq = qnormalize(xq);
     }
-    const m33 R = q2m(xq);
+    STAMP(2);   // K
     v3 xi;
     {
       const float4 c_ipos = M.b_ipos[blo];
-      xi = add3(xp, mrot(R, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
+      xi = add3(xp, qrot(xq, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
     }
     // ---- C: tree CoM (wave reduction, result is wave-uniform), cinert, cdof
     const float mass = isb ? M.b_pos_mass[blo].w : 0.f;
@@ -491,14 +512,13 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     com.x = bcast(wave_sum(mass * xi.x), 0) * M.mtot_inv;
     com.y = bcast(wave_sum(mass * xi.y), 0) * M.mtot_inv;
     com.z = bcast(wave_sum(mass * xi.z), 0) * M.mtot_inv;
-    float ci[10];
+    float iw[6];     // world-frame inertia about the body's own CoM
     {
       const float4 c_iquat = M.b_iquat[blo];
       const float4 c_inertia = M.b_inertia[blo];
       q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
       const m33 Ri = q2m(qmul(xq, iq));
       const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
-      float iw[6];     // world-frame inertia about the body's own CoM
       iw[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2;
       iw[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2;
       iw[2] = Ri.a[6] * Ri.a[6] * i0 + Ri.a[7] * Ri.a[7] * i1 + Ri.a[8] * Ri.a[8] * i2;
@@ -509,15 +529,6 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
 #pragma unroll
         for (int k = 0; k < 6; k++) iw[k] = 0.f;
       }
-      // cinert about the tree CoM (MuJoCo's form) stays in registers for the RNE part
-      const v3 d = sub3(xi, com);
-      ci[0] = iw[0] + mass * (d.y * d.y + d.z * d.z);
-      ci[1] = iw[1] + mass * (d.x * d.x + d.z * d.z);
-      ci[2] = iw[2] + mass * (d.x * d.x + d.y * d.y);
-      ci[3] = iw[3] - mass * d.x * d.y;
-      ci[4] = iw[4] - mass * d.x * d.z;
-      ci[5] = iw[5] - mass * d.y * d.z;
-      ci[6] = mass * d.x; ci[7] = mass * d.y; ci[8] = mass * d.z; ci[9] = mass;
       if (lane < nb) {
         // LDS gets the LOCAL description (inertia about the body's own CoM, CoM, mass): S assembles each
         // composite inertia about its own subtree CoM, avoiding the m*d^2 inflation (and the fp32
@@ -527,22 +538,24 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         *(float2*)(CI + lane * 12 + 8) = make_float2(xi.z, mass);
       }
     }
+    STAMP(3);   // C
     // ---- V: joint velocity vJ, then cvel = chain sum of vJ, cacc = a0 + chain sum of cvel_parent x vJ
     s6 cv, ca;
     {
       s6 vJ = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
       s6 vt = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};       // translational part of a free root
       if (jtype == FMJ_JNT_HINGE || jtype == FMJ_JNT_SLIDE) {
-        const v3 axw = mrot(R, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
+        const v3 axw = qrot(xq, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
         s6 cd;
         if (jtype == FMJ_JNT_HINGE) {
-          const v3 anchor = add3(xp, mrot(R, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
+          const v3 anchor = add3(xp, qrot(xq, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
           cd.r = axw; cd.l = cross(axw, sub3(com, anchor));
         } else { cd.r = mk3(0.f, 0.f, 0.f); cd.l = axw; }
         lds_put6(CD + dadr * 8, cd);
         vJ = s6scl(cd, QV[dadr]);
       } else if (jtype == FMJ_JNT_FREE) {
         const v3 off = sub3(com, xp);
+        const m33 R = q2m(xq);
         vt.l = mk3(QV[dadr], QV[dadr + 1], QV[dadr + 2]);
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -580,9 +593,20 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       ca.l = sub3(ca.l, mk3(M.gx, M.gy, M.gz));
       if (!isb) { cv.r = cv.l = mk3(0.f, 0.f, 0.f); }
     }
+    STAMP(4);   // V
     // ---- F: body force (inertial minus external), about the common point
     {
-      s6 f = s6add(inert_mul(ci, ca), cross_force(cv, inert_mul(ci, cv)));
+      // cinert * v with cinert = {Iw, d = xi - com, m} (MuJoCo's cinert about the tree CoM, never materialised):
+      // lin = p = m (u + w x d),  rot = Iw w + d x p
+      const v3 d = sub3(xi, com);
+      s6 ia, iv;
+      ia.l = scl3(add3(ca.l, cross(ca.r, d)), mass);
+      ia.r = add3(mk3(iw[0] * ca.r.x + iw[3] * ca.r.y + iw[4] * ca.r.z, iw[3] * ca.r.x + iw[1] * ca.r.y + iw[5] * ca.r.z,
+                      iw[4] * ca.r.x + iw[5] * ca.r.y + iw[2] * ca.r.z), cross(d, ia.l));
+      iv.l = scl3(add3(cv.l, cross(cv.r, d)), mass);
+      iv.r = add3(mk3(iw[0] * cv.r.x + iw[3] * cv.r.y + iw[4] * cv.r.z, iw[3] * cv.r.x + iw[1] * cv.r.y + iw[5] * cv.r.z,
+                      iw[4] * cv.r.x + iw[5] * cv.r.y + iw[2] * cv.r.z), cross(d, iv.l));
+      s6 f = s6add(ia, cross_force(cv, iv));
       const v3 fw = mk3(xf[0], xf[1], xf[2]), tw = mk3(xf[3], xf[4], xf[5]);
       f.r = sub3(f.r, add3(tw, cross(sub3(xi, com), fw)));
       f.l = sub3(f.l, fw);
@@ -611,6 +635,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
     }
     WSYNC();
+    STAMP(5);   // F + carry
     // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize): accumulated force
     // (about the tree CoM) and composite inertia about the body's own CoM, shifted to the subtree CoM.
     {
@@ -652,6 +677,8 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
     }
     WSYNC();
+    STAMP(6);   // S
+    for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HR + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // see L
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
     float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
@@ -715,82 +742,132 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       }
     }
     WSYNC();
+    STAMP(7);   // Q
     // ---- M: H entries, one per lane per round: M_ij = w_j . (I_s w_i) + v_j(s) . (m v_i(s)), s = subtree CoM of dof i's body
+    {
+      constexpr int MAXR = 8;                         // table entries for up to 8 rounds are fetched up front
+      uint32_t tt[MAXR]; float ta[MAXR];
+#pragma unroll
+      for (int rr = 0; rr < MAXR; rr++) {
+        const int e = lane + 64 * rr;
+        tt[rr] = e < M.nMpad ? M.m_tab[e] : 0u;
+        ta[rr] = e < M.nMpad ? M.m_add[e] : 0.f;
+      }
+#pragma unroll
+      for (int rr = 0; rr < MAXR; rr++) {
+        const uint32_t t = tt[rr];
+        if (t >> 24) {
+          const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
+          const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
+          const float2 sxy = *(const float2*)(CI + body * 12 + 6);
+          const float sz = CI[body * 12 + 8];
+          const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
+          HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + ta[rr];
+        }
+      }
 #pragma unroll 1
-    for (int e = lane; e < M.nMpad; e += 64) {
-      const uint32_t t = M.m_tab[e];
-      if (t >> 24) {
-        const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
-        const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
-        const float2 sxy = *(const float2*)(CI + body * 12 + 6);
-        const float sz = CI[body * 12 + 8];
-        const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
-        HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + M.m_add[e];
+      for (int e = lane + 64 * MAXR; e < M.nMpad; e += 64) {     // models with more than 512 entries
+        const uint32_t t = M.m_tab[e];
+        if (t >> 24) {
+          const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
+          const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
+          const float2 sxy = *(const float2*)(CI + body * 12 + 6);
+          const float sz = CI[body * 12 + 8];
+          const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
+          HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + M.m_add[e];
+        }
       }
     }
     WSYNC();
-    // ---- L: L'DL with register rows, pivot row k broadcast through LDS.
+    STAMP(8);   // M
+    // ---- L: L'DL with register rows.  Lane i owns row i (depth-indexed, UNSCALED: entries are L*D); at pivot k
+    // lane k publishes its final row in HR, every lane reads it back in one batch of LDS reads and the
+    // ancestors of k update their rows.  The diagonal is tracked in its own register so D_k comes from a
+    // v_readlane before the LDS round trip.  Slots past a lane's depth only ever hold finite garbage that is
+    // never read as a matrix entry (HR is zero-filled at the top of every step).
     float my_qacc;
     {
       float r[MAXD];
 #pragma unroll
       for (int d = 0; d < MAXD; d += 4) {
         float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (d < RS && isd) t = *(const float4*)(HR + lane * RS + d);
-        // slots past the lane's own depth collect -t*rk garbage during elimination: never read as
-        // matrix entries, but they must not carry over from step to step (they would grow by 1/D each step)
-        r[d] = d <= ddepth ? t.x : 0.f; r[d + 1] = d + 1 <= ddepth ? t.y : 0.f;
-        r[d + 2] = d + 2 <= ddepth ? t.z : 0.f; r[d + 3] = d + 3 <= ddepth ? t.w : 0.f;
+        if (isd) t = *(const float4*)(HR + lane * RS + d);
+        r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
       }
+      float diag = isd ? HR[lane * RS + ddepth] : 1.f;
       float dinv_mine = 0.f;
 #pragma unroll 1
       for (int k = nv - 1; k >= 0; k--) {
-        const int depk = __builtin_amdgcn_readlane(ddepth, k);
-        if (lane == k) {
-#pragma unroll
-          for (int d = 0; d < MAXD; d += 4) if (d <= depk) *(float4*)(RK + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
-        }
-        WSYNC();
-        const float dk_inv = 1.0f / RK[depk];
-        const bool anc = lane < k && k < lane + dsub;
-        const float t = anc ? RK[ddepth] * dk_inv : 0.f;
-#pragma unroll
-        for (int d = 0; d < MAXD; d += 4) {
-          if (d <= depk) {
-            const float4 rk = *(const float4*)(RK + d);
-            r[d] = fmaf(-t, rk.x, r[d]); r[d + 1] = fmaf(-t, rk.y, r[d + 1]);
-            r[d + 2] = fmaf(-t, rk.z, r[d + 2]); r[d + 3] = fmaf(-t, rk.w, r[d + 3]);
-          }
-        }
+        const float Dk = bcast(diag, k);
+        float dk_inv = __builtin_amdgcn_rcpf(Dk);
+        dk_inv = dk_inv * (2.0f - Dk * dk_inv);          // one Newton step: full fp32 accuracy
         if (lane == k) {
           dinv_mine = dk_inv;
 #pragma unroll
-          for (int d = 0; d < MAXD; d += 4) if (d <= depk)
-            *(float4*)(HR + lane * RS + d) = make_float4(r[d] * dk_inv, r[d + 1] * dk_inv, r[d + 2] * dk_inv, r[d + 3] * dk_inv);
+          for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
         }
         WSYNC();
+        const float tk = HR[k * RS + ddepth];
+        float4 rk[MAXD / 4];
+#pragma unroll
+        for (int g = 0; g < MAXD / 4; g++) rk[g] = *(const float4*)(HR + k * RS + 4 * g);
+        const bool anc = lane < k && k < lane + dsub;
+        const float t = anc ? tk * dk_inv : 0.f;
+        // all groups, unconditionally: straight-line code beats skipping the (on average 40 %) padding groups
+#pragma unroll
+        for (int g = 0; g < MAXD / 4; g++) {
+          r[4 * g] = fmaf(-t, rk[g].x, r[4 * g]); r[4 * g + 1] = fmaf(-t, rk[g].y, r[4 * g + 1]);
+          r[4 * g + 2] = fmaf(-t, rk[g].z, r[4 * g + 2]); r[4 * g + 3] = fmaf(-t, rk[g].w, r[4 * g + 3]);
+        }
+        diag = fmaf(-t, tk, diag);
+        WSYNC();
       }
-      // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts
+      STAMP(9);   // L
+      // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts; HR rows hold L*D, so 1/D is folded in
       float x = qfrc;
+      const int dli = isd ? lane : 0;                 // in-bounds row for idle lanes; their result is discarded
+      {
+        int i = nv - 1;
+        for (; i >= 8; i -= 8) {                       // batches of 8 pivots: the 8 LDS reads do not depend on x
+          float l[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) l[u] = HR[(i - u) * RS + ddepth];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const bool anc = lane < i - u && i - u < lane + dsub;
+            x = fmaf(anc ? -l[u] : 0.f, bcast(x, i - u) * bcast(dinv_mine, i - u), x);
+          }
+        }
 #pragma unroll 1
-      for (int i = nv - 1; i >= 1; i--) {
-        const float xi_ = bcast(x, i);
-        const bool anc = lane < i && i < lane + dsub;
-        const float l = anc ? HR[i * RS + ddepth] : 0.f;
-        x = fmaf(-l, xi_, x);
+        for (; i >= 1; i--) {
+          const float l = (lane < i && i < lane + dsub) ? HR[i * RS + ddepth] : 0.f;
+          x = fmaf(-l, bcast(x, i) * bcast(dinv_mine, i), x);
+        }
       }
       x *= dinv_mine;
+      {
+        int j = 0;
+        for (; j + 8 <= nv - 1; j += 8) {
+          float l[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) l[u] = HR[dli * RS + __builtin_amdgcn_readlane(ddepth, j + u)];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int subj = __builtin_amdgcn_readlane(dsub, j + u);
+            const bool desc = isd && j + u < lane && lane < j + u + subj;
+            x = fmaf(desc ? -l[u] * dinv_mine : 0.f, bcast(x, j + u), x);
+          }
+        }
 #pragma unroll 1
-      for (int j = 0; j < nv - 1; j++) {
-        const float xj = bcast(x, j);
-        const int depj = __builtin_amdgcn_readlane(ddepth, j);
-        const int subj = __builtin_amdgcn_readlane(dsub, j);
-        const bool desc = isd && j < lane && lane < j + subj;
-        const float l = desc ? HR[lane * RS + depj] : 0.f;
-        x = fmaf(-l, xj, x);
+        for (; j < nv - 1; j++) {
+          const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
+          const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] * dinv_mine : 0.f;
+          x = fmaf(-l, bcast(x, j), x);
+        }
       }
       my_qacc = x;
     }
+    STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
     const float hstep = A.integrate ? M.h : 0.f;     // fmj_forward: mj_forward only
     if (isd) {
@@ -821,6 +898,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
     }
     WSYNC();
+    STAMP(11);  // Euler
   }
 
   // ---- store state ---------------------------------------------------------------------------------------
@@ -829,6 +907,12 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
   for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
   for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
   if (A.qacc) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
+#ifdef FMJ_STAMPS
+  if (env == 0 && lane == 0 && A.qacc) {
+#pragma unroll
+    for (int i = 0; i < NSTAMP; i++) A.qacc[i] = stamp_acc[i];
+  }
+#endif
   if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * A.n_steps;
   if (__ballot(warn != 0)) {
     int w = warn;
@@ -931,7 +1015,8 @@ typedef void (*step_kernel_t)(const DevModel, const StepArgs);
 template <bool FUSED>
 static step_kernel_t pick_step_kernel(int rs) {
   switch (rs) {
-    case 4: case 8: return fmj_step_kernel<FUSED, 8>;
+    case 4: return fmj_step_kernel<FUSED, 4>;
+    case 8: return fmj_step_kernel<FUSED, 8>;
     case 12: return fmj_step_kernel<FUSED, 12>;
     case 16: return fmj_step_kernel<FUSED, 16>;
     case 20: return fmj_step_kernel<FUSED, 20>;
