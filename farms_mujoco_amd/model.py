@@ -657,7 +657,7 @@ def eel(n_joints: int = 20, timestep: float = 1e-3) -> Model:
             b.add_body(f'body_{i}', f'body_{i-1}', joint='hinge', jname=f'joint_body_{i}', axis=(0, 0, 1),
                        damping=5e-4, **kw)
         a = r/0.015
-        b.set_swimming(f'body_{i}', drag_coefficients=[[-0.01*a, -0.8*a, -0.8*a], [-1e-5, -1e-4, -1e-4]],
+        b.set_swimming(f'body_{i}', drag_coefficients=[[-0.01*a, -0.8*a, -0.8*a], [-1e-7, -2e-6, -2e-6]],
                        height=0.5*(L/2 + r))
     for i in range(1, n):
         b.add_position_actuator(f'joint_body_{i}', kp=0.5)
