@@ -297,6 +297,99 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   return L;
 }
 
+// ---- sparse L'DL on depth-indexed rows (MuJoCo's mj_factorI / mj_solveLD on the dof tree) --------------------
+// Lane i owns row i in registers (UNSCALED: entries are L*D). At pivot k lane k publishes its final row in HR,
+// every lane reads it back in one batch of LDS reads and the ancestors of k update their rows.  The diagonal is
+// tracked in its own register so D_k comes from a v_readlane before the LDS round trip.  Slots past a lane's
+// depth only ever hold finite garbage that is never read as a matrix entry (the caller zero-fills HR before
+// assembling the matrix).  On return HR holds the final rows (L*D) and dinv = 1/D_lane.
+template <int MAXD>
+__device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int ddepth, int dsub, int nv, float (&r)[MAXD], float& dinv_mine) {
+  constexpr int RS = MAXD;
+#pragma unroll
+  for (int d = 0; d < MAXD; d += 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (isd) t = *(const float4*)(HR + lane * RS + d);
+    r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
+  }
+  float diag = isd ? HR[lane * RS + ddepth] : 1.f;
+  dinv_mine = 0.f;
+#pragma unroll 1
+  for (int k = nv - 1; k >= 0; k--) {
+    const float Dk = bcast(diag, k);
+    float dk_inv = __builtin_amdgcn_rcpf(Dk);
+    dk_inv = dk_inv * (2.0f - Dk * dk_inv);          // one Newton step: full fp32 accuracy
+    if (lane == k) {
+      dinv_mine = dk_inv;
+#pragma unroll
+      for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
+    }
+    WSYNC();
+    const float tk = HR[k * RS + ddepth];
+    float4 rk[MAXD / 4];
+#pragma unroll
+    for (int g = 0; g < MAXD / 4; g++) rk[g] = *(const float4*)(HR + k * RS + 4 * g);
+    const bool anc = lane < k && k < lane + dsub;
+    const float t = anc ? tk * dk_inv : 0.f;
+    // all groups, unconditionally: straight-line code beats skipping the (on average 40 %) padding groups
+#pragma unroll
+    for (int g = 0; g < MAXD / 4; g++) {
+      r[4 * g] = fmaf(-t, rk[g].x, r[4 * g]); r[4 * g + 1] = fmaf(-t, rk[g].y, r[4 * g + 1]);
+      r[4 * g + 2] = fmaf(-t, rk[g].z, r[4 * g + 2]); r[4 * g + 3] = fmaf(-t, rk[g].w, r[4 * g + 3]);
+    }
+    diag = fmaf(-t, tk, diag);
+    WSYNC();
+  }
+}
+
+// x = (L' D L)^-1 rhs with v_readlane broadcasts; HR rows hold L*D, so 1/D is folded in.
+template <int MAXD>
+__device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane, bool isd, int ddepth, int dsub, int nv, float dinv_mine) {
+  constexpr int RS = MAXD;
+  float x = rhs;
+  const int dli = isd ? lane : 0;                 // in-bounds row for idle lanes; their result is discarded
+  {
+    int i = nv - 1;
+    for (; i >= 8; i -= 8) {                       // batches of 8 pivots: the 8 LDS reads do not depend on x
+      float l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = HR[(i - u) * RS + ddepth];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const bool anc = lane < i - u && i - u < lane + dsub;
+        x = fmaf(anc ? -l[u] : 0.f, bcast(x, i - u) * bcast(dinv_mine, i - u), x);
+      }
+    }
+#pragma unroll 1
+    for (; i >= 1; i--) {
+      const float l = (lane < i && i < lane + dsub) ? HR[i * RS + ddepth] : 0.f;
+      x = fmaf(-l, bcast(x, i) * bcast(dinv_mine, i), x);
+    }
+  }
+  x *= dinv_mine;
+  {
+    int j = 0;
+    for (; j + 8 <= nv - 1; j += 8) {
+      float l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) l[u] = HR[dli * RS + __builtin_amdgcn_readlane(ddepth, j + u)];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int subj = __builtin_amdgcn_readlane(dsub, j + u);
+        const bool desc = isd && j + u < lane && lane < j + u + subj;
+        x = fmaf(desc ? -l[u] * dinv_mine : 0.f, bcast(x, j + u), x);
+      }
+    }
+#pragma unroll 1
+    for (; j < nv - 1; j++) {
+      const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
+      const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] * dinv_mine : 0.f;
+      x = fmaf(-l, bcast(x, j), x);
+    }
+  }
+  return x;
+}
+
 // Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
 // forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
 // every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
@@ -780,92 +873,14 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     }
     WSYNC();
     STAMP(8);   // M
-    // ---- L: L'DL with register rows.  Lane i owns row i (depth-indexed, UNSCALED: entries are L*D); at pivot k
-    // lane k publishes its final row in HR, every lane reads it back in one batch of LDS reads and the
-    // ancestors of k update their rows.  The diagonal is tracked in its own register so D_k comes from a
-    // v_readlane before the LDS round trip.  Slots past a lane's depth only ever hold finite garbage that is
-    // never read as a matrix entry (HR is zero-filled at the top of every step).
+    // ---- L + X: sparse L'DL of H = M + diag(armature + h*damping) and the solve H qacc = qfrc_smooth
     float my_qacc;
     {
       float r[MAXD];
-#pragma unroll
-      for (int d = 0; d < MAXD; d += 4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (isd) t = *(const float4*)(HR + lane * RS + d);
-        r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
-      }
-      float diag = isd ? HR[lane * RS + ddepth] : 1.f;
-      float dinv_mine = 0.f;
-#pragma unroll 1
-      for (int k = nv - 1; k >= 0; k--) {
-        const float Dk = bcast(diag, k);
-        float dk_inv = __builtin_amdgcn_rcpf(Dk);
-        dk_inv = dk_inv * (2.0f - Dk * dk_inv);          // one Newton step: full fp32 accuracy
-        if (lane == k) {
-          dinv_mine = dk_inv;
-#pragma unroll
-          for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
-        }
-        WSYNC();
-        const float tk = HR[k * RS + ddepth];
-        float4 rk[MAXD / 4];
-#pragma unroll
-        for (int g = 0; g < MAXD / 4; g++) rk[g] = *(const float4*)(HR + k * RS + 4 * g);
-        const bool anc = lane < k && k < lane + dsub;
-        const float t = anc ? tk * dk_inv : 0.f;
-        // all groups, unconditionally: straight-line code beats skipping the (on average 40 %) padding groups
-#pragma unroll
-        for (int g = 0; g < MAXD / 4; g++) {
-          r[4 * g] = fmaf(-t, rk[g].x, r[4 * g]); r[4 * g + 1] = fmaf(-t, rk[g].y, r[4 * g + 1]);
-          r[4 * g + 2] = fmaf(-t, rk[g].z, r[4 * g + 2]); r[4 * g + 3] = fmaf(-t, rk[g].w, r[4 * g + 3]);
-        }
-        diag = fmaf(-t, tk, diag);
-        WSYNC();
-      }
+      float dinv_mine;
+      ldl_factor<MAXD>(HR, lane, isd, ddepth, dsub, nv, r, dinv_mine);
       STAMP(9);   // L
-      // ---- X: solve (L' D L) x = qfrc with v_readlane broadcasts; HR rows hold L*D, so 1/D is folded in
-      float x = qfrc;
-      const int dli = isd ? lane : 0;                 // in-bounds row for idle lanes; their result is discarded
-      {
-        int i = nv - 1;
-        for (; i >= 8; i -= 8) {                       // batches of 8 pivots: the 8 LDS reads do not depend on x
-          float l[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) l[u] = HR[(i - u) * RS + ddepth];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const bool anc = lane < i - u && i - u < lane + dsub;
-            x = fmaf(anc ? -l[u] : 0.f, bcast(x, i - u) * bcast(dinv_mine, i - u), x);
-          }
-        }
-#pragma unroll 1
-        for (; i >= 1; i--) {
-          const float l = (lane < i && i < lane + dsub) ? HR[i * RS + ddepth] : 0.f;
-          x = fmaf(-l, bcast(x, i) * bcast(dinv_mine, i), x);
-        }
-      }
-      x *= dinv_mine;
-      {
-        int j = 0;
-        for (; j + 8 <= nv - 1; j += 8) {
-          float l[8];
-#pragma unroll
-          for (int u = 0; u < 8; u++) l[u] = HR[dli * RS + __builtin_amdgcn_readlane(ddepth, j + u)];
-#pragma unroll
-          for (int u = 0; u < 8; u++) {
-            const int subj = __builtin_amdgcn_readlane(dsub, j + u);
-            const bool desc = isd && j + u < lane && lane < j + u + subj;
-            x = fmaf(desc ? -l[u] * dinv_mine : 0.f, bcast(x, j + u), x);
-          }
-        }
-#pragma unroll 1
-        for (; j < nv - 1; j++) {
-          const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
-          const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] * dinv_mine : 0.f;
-          x = fmaf(-l, bcast(x, j), x);
-        }
-      }
-      my_qacc = x;
+      my_qacc = ldl_solve<MAXD>(HR, qfrc, lane, isd, ddepth, dsub, nv, dinv_mine);
     }
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
