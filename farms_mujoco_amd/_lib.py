@@ -24,7 +24,8 @@ class FmjError(RuntimeError):
 
 class CData(ctypes.Structure):
     _fields_ = [(n, _VP) for n in ('qpos', 'qvel', 'ctrl', 'qpos_spring', 'xfrc_applied', 'xpos', 'xquat',
-                                   'xipos', 'sensordata', 'qacc', 'time', 'status')]
+                                   'xipos', 'sensordata', 'qacc', 'time', 'status', 'qacc_warmstart', 'contact',
+                                   'ncon')]
 
 
 class CSensorLayout(ctypes.Structure):
@@ -73,6 +74,8 @@ SYMBOLS = {
     'fmj_drag': (ctypes.c_int, [_VP, ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits), _VP, _VP]),
     'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
                                         ctypes.c_int32, _VP]),
+    'fmj_set_contact_maps': (ctypes.c_int, [_VP, ctypes.c_int32, _I, ctypes.c_int32, _I]),
+    'fmj_contacts2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits), _VP]),
     'fmj_step_fused': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CFusedArgs), _VP]),
     'fmj_sc': (ctypes.c_int, [ctypes.c_char_p]),
 }

@@ -79,11 +79,29 @@ struct DevModel {
   const float4* s_c0;         // clin xyz, mass
   const float4* s_c1;         // cang xyz, height
   const float4* s_c2;         // density, links_index, xfrc_index, body
+  // ---- constraint path (joint limits, plane contacts, pyramidal cone, PGS) ----
+  int cons;                   // 1 if the model has limits or collision geoms
+  int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
+  float solver_tolerance, pgs_scale, impratio_isqrt;
+  const int4* g_info;         // [ngeom] type, body, last dof on the body's chain (-1 none), -
+  const float4* g_size;       // [ngeom] size xyz, friction[0]
+  const float4* g_pos;        // [ngeom] pos xyz, translational invweight0 of the body
+  const float4* g_quat;       // [ngeom]
+  const float4* g_sol0;       // [ngeom] solref0, solref1, solimp0, solimp1
+  const float4* g_sol1;       // [ngeom] solimp2, solimp3, solimp4, -
+  const float4* p_plane;      // [nplane] unit normal xyz, offset n.p0  (static planes on the world body)
+  const float4* p_prm;        // [nplane] friction[0], translational invweight0 (0), geom id bits, -
+  const float4* d_lim;        // [nv] limited flag, range lo, range hi, margin   (hinge/slide dofs)
+  const float4* d_sol0;       // [nv] solref0, solref1, solimp0, solimp1
+  const float4* d_sol1;       // [nv] solimp2, solimp3, solimp4, dof_invweight0
+  const float* m_arm;         // [nMpad] armature on the diagonal entries (M itself, without h*damping)
+  const int* d_parent;        // [64] dof_parentid
 };
 
 struct StepArgs {
   float* qpos; float* qvel; const float* ctrl; const float* qpos_spring; const float* xfrc_applied;
   float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
+  float* qacc_warmstart; float* contact; int* ncon; float* contacts_rows; float inv_newtons;
   int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
   long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc;
   float* links; float* joints; float* xfrc; float* xfrc_applied_out;
@@ -107,6 +125,7 @@ struct fmj_ctx {
   int4* d_b_info2; int4* d_d_info;
   int nbody, nv, nu, njnt;
   std::vector<int> jnt_dofadr, jnt_type;
+  int ngeom, n_contact_rows, n_pairs; std::vector<int> geom_sensor, geom_is_plane; int* d_geom_sensor; int* d_pairs;
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -205,6 +224,7 @@ __device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wa
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 // LDS ordering between lanes of the one wave that forms the workgroup
 #define WSYNC() __syncthreads()
+#define WSYNC_LOCAL() __builtin_amdgcn_wave_barrier()
 
 __device__ __forceinline__ void lds_put6(float* p, s6 v) {
   *(float4*)p = make_float4(v.r.x, v.r.y, v.r.z, v.l.x);
@@ -275,9 +295,11 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
-  int P1, P2, CI, CD, HR, RK, QP, QV, XV, VT, ANC, CY, total;
+  int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
+  int HM, YJ, EP, CT, XS, WW, QW, DI, PO;      // constraint path only
 };
-__host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride) {
+__host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
+                                                int maxcon = 0, int nvs = 0) {
   LdsLayout L;
   const int nmax = nb > nv ? nb : nv;
   int o = 0;
@@ -285,14 +307,25 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
   L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
   L.CD = o; o += nv * 8;              // cdof
-  L.HR = o; o += nv * rs;             // depth-indexed rows of H, then L
-  L.RK = o; o += FMJ_MAXD;            // broadcast pivot row (sized for the largest instantiation)
+  L.HR = o; o += nv * rs;             // depth-indexed rows of H = M + h B, then its L'DL
   L.QP = o; o += r4(nq);
   L.QV = o; o += r4(nv);
   L.XV = o; o += r4(nv);
   L.VT = o; o += 8;
   L.ANC = o; o += r4(nb * anc_stride) / 4;
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
+  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = o;
+  if (cons) {
+    L.HM = o; o += nv * rs;           // rows of M, then its L'DL
+    L.YJ = o; o += r4(maxefc * nvs);  // constraint Jacobian rows J, then Y = J L^-1
+    L.EP = o; o += maxefc * 8;        // per row: pos, margin/aref, R, b, force, diagA, type|id, mu
+    L.CT = o; o += maxcon * 16;       // contacts: pos(3) normal(3) t1(3) t2(3) dist mu geom plane
+    L.XS = o; o += r4(nv);            // qacc_smooth
+    L.WW = o; o += r4(nv);            // w = D^-1 Y' f
+    L.QW = o; o += r4(nv);            // qacc_warmstart
+    L.DI = o; o += r4(nv);            // 1/D of the M factor
+    L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
+  }
   L.total = o;
   return L;
 }
@@ -390,6 +423,51 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
   return x;
 }
 
+// ---- constraint path: joint limits + plane contacts, pyramidal cone, PGS ----------
+// Rows live in LDS: YJ[e][nvs] holds J_e and is transformed in place to Y_e = J_e L^-1 (M = L'DL), so that
+// A = J M^-1 J' = Y D^-1 Y' is never formed: PGS keeps w = D^-1 Y' f (lane = dof) and a row residual is
+// b_e + y_e . w + R_e f_e.  EP[e][8] = {pos, aref, R, b, force, diagA, type|id bits, mu}.
+
+__device__ __forceinline__ float wave_sum_fast(float v) {   // DPP reduction, total broadcast from lane 63
+  int x = __float_as_int(v);
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xB1, 0xF, 0xF, true));  x = __float_as_int(v);   // quad_perm [1,0,3,2]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x4E, 0xF, 0xF, true));  x = __float_as_int(v);   // quad_perm [2,3,0,1]
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x141, 0xF, 0xF, true)); x = __float_as_int(v);   // row_half_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x140, 0xF, 0xF, true)); x = __float_as_int(v);   // row_mirror
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, true)); x = __float_as_int(v);   // row_bcast:15
+  v += __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, true));                          // row_bcast:31
+  return bcast(v, 63);
+}
+
+__device__ __forceinline__ float impedance(float d0, float d1, float width, float mid, float power, float pos, float margin) {
+  d0 = fminf(fmaxf(d0, 1e-4f), 0.9999f); d1 = fminf(fmaxf(d1, 1e-4f), 0.9999f);
+  width = fmaxf(0.f, width); mid = fminf(fmaxf(mid, 1e-4f), 0.9999f); power = fmaxf(1.f, power);
+  if (d0 == d1 || width <= 1e-15f) return 0.5f * (d0 + d1);
+  const float x = fabsf((pos - margin) / width);
+  float y;
+  if (x >= 1.f) y = 1.f;
+  else if (x <= 0.f) y = 0.f;
+  else if (power == 1.f) y = x;
+  else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
+  else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
+  return d0 + y * (d1 - d0);
+}
+
+// R and the (K*imp, B) pair of one row from solref / solimp (mj_makeImpedance)
+__device__ __forceinline__ void row_params(float sr0, float sr1, float si0, float si1, float si2, float si3, float si4,
+                                           float pos, float margin, float diag_approx, float h, float* R, float* kimp, float* bb) {
+  const float imp = impedance(si0, si1, si2, si3, si4, pos, margin);
+  const float dmax = fminf(fmaxf(si1, 1e-4f), 0.9999f);
+  float K, B;
+  if (sr0 > 0.f) {
+    const float tc = fmaxf(sr0, 2.f * h);
+    K = 1.f / fmaxf(1e-15f, dmax * dmax * tc * tc * sr1 * sr1);
+    B = 2.f / fmaxf(1e-15f, dmax * tc);
+  } else { K = -sr0 / fmaxf(1e-15f, dmax * dmax); B = -sr1 / fmaxf(1e-15f, dmax); }
+  *R = fmaxf(1e-15f, (1.f - imp) * diag_approx / imp);
+  *kimp = K * imp; *bb = B;
+}
+
 // Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
 // forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
 // every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
@@ -437,26 +515,29 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 #define STAMP(i)
 #endif
 
-template <bool FUSED, int MAXD>
-__global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
+template <bool FUSED, int MAXD, bool CONS>
+__global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
-  const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride);
+  const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride, CONS ? 1 : 0, M.maxefc, M.max_contacts, M.nvs);
   float* T = lds + LL.P1;  float* F = T;       // T (transforms) -> W (acceleration scan) -> F (body force)
   float* V = lds + LL.P2;  float* BUF = V;     // V (velocity scan) -> BUF (I w, m v)
   float* CI = lds + LL.CI;
   float* CD = lds + LL.CD;
   float* HR = lds + LL.HR;
-  float* RK = lds + LL.RK;
   float* QP = lds + LL.QP;
   float* QV = lds + LL.QV;
   float* XV = lds + LL.XV;
   float* VT = lds + LL.VT;
   const uint8_t* JMP = (const uint8_t*)(lds + LL.ANC);   // [nb][anc_stride]: ancestor at distance 2^r
   float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
+  float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EP = lds + LL.EP;  float* CT = lds + LL.CT;
+  float* XS = lds + LL.XS;  float* WW = lds + LL.WW;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
+  float* PO = lds + LL.PO;
+  const int nvs = M.nvs;
 
   const bool isb = lane > 0 && lane < nb;
   const int bl = isb ? lane : 0;
@@ -466,6 +547,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
   const int4 d_info0 = M.d_info[dl];
   const int ddepth = isd ? d_info0.y : 0;
   const int dsub = isd ? d_info0.z : 0;
+  const int dparent = (CONS && isd) ? M.d_parent[dl] : 0;
 
   // ---- load tables + state -------------------------------------------------------------------------
   {
@@ -479,7 +561,10 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     for (int i = lane; i < nq; i += 64) QP[i] = gq[i];
     for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
     if (lane < 8) VT[lane] = 0.f;
+    if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
   }
+  float cy_limfrc = 0.f;                            // carried joint-limit force of this dof's joint (physics.py:484-487)
+  if (CONS && FUSED && isd) { const int4 da0 = M.d_act[dl]; if (M.d_prm[dl].w != 0.f) cy_limfrc = A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
   float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
   float cy_actsum = 0.f;                            // carried motor torque (physics.py:510-524)
   if (FUSED) {
@@ -544,7 +629,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         row[FMJ_JOINT_POSITION] = QP[__float_as_int(dp.z)];
         row[FMJ_JOINT_VELOCITY] = QV[lane] * A.inv_angvel;
         row[FMJ_JOINT_TORQUE] = cy_actsum;
-        row[FMJ_JOINT_LIMIT_FORCE] = 0.f;
+        row[FMJ_JOINT_LIMIT_FORCE] = cy_limfrc;
       }
     }
 
@@ -592,6 +677,10 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         WSYNC();
       }
       xq = qnormalize(xq);
+      if (CONS && lane < nb) {
+        *(float4*)(PO + lane * 8) = make_float4(xp.x, xp.y, xp.z, 0.f);
+        *(float4*)(PO + lane * 8 + 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
+      }
     }
     STAMP(2);   // K
     v3 xi;
@@ -771,7 +860,8 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
     }
     WSYNC();
     STAMP(6);   // S
-    for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HR + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // see L
+    for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HR + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // see ldl_factor
+    if (CONS) for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HM + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
     float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
@@ -855,7 +945,9 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
           const float2 sxy = *(const float2*)(CI + body * 12 + 6);
           const float sz = CI[body * 12 + 8];
           const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
-          HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + ta[rr];
+          const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
+          HR[i * RS + dep] = mij + ta[rr];
+          if (CONS) HM[i * RS + dep] = mij + M.m_arm[lane + 64 * rr];
         }
       }
 #pragma unroll 1
@@ -867,12 +959,250 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
           const float2 sxy = *(const float2*)(CI + body * 12 + 6);
           const float sz = CI[body * 12 + 8];
           const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
-          HR[i * RS + dep] = dot3(cdj.r, bf.r) + dot3(vj, bf.l) + M.m_add[e];
+          const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
+          HR[i * RS + dep] = mij + M.m_add[e];
+          if (CONS) HM[i * RS + dep] = mij + M.m_arm[e];
         }
       }
     }
     WSYNC();
     STAMP(8);   // M
+    // ---- constraints (CONS instantiation only): qfrc_constraint from limits + plane contacts via PGS
+    float qfrc_c = 0.f;
+    if (CONS) {
+      const float h = M.h;
+      // (1) factor M, qacc_smooth = M^-1 qfrc_smooth
+      float dinv_m;
+      {
+        float rm[MAXD];
+        ldl_factor<MAXD>(HM, lane, isd, ddepth, dsub, nv, rm, dinv_m);
+      }
+      const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
+      if (isd) { XS[lane] = xs; DI[lane] = dinv_m; }
+      // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
+      const float4 lim = M.d_lim[dlo];
+      float dist_lo = 0.f, dist_hi = 0.f; bool act_lo = false, act_hi = false;
+      if (d_scalar && lim.x != 0.f) {
+        const float qj = QP[d_qadr];
+        dist_lo = qj - lim.y; dist_hi = lim.z - qj;
+        act_lo = dist_lo < lim.w; act_hi = dist_hi < lim.w;
+      }
+      const unsigned long long m_lo = __ballot(act_lo), m_hi = __ballot(act_hi);
+      const unsigned long long lt = (1ull << lane) - 1ull;
+      const int e_lo = __popcll(m_lo & lt) + __popcll(m_hi & lt);
+      const int e_hi = e_lo + (act_lo ? 1 : 0);
+      const int nlim = __popcll(m_lo) + __popcll(m_hi);
+      // (3) plane contacts: lane = geom; contacts ordered by (plane, geom, segment) like the oracle
+      int ncon = 0;
+      for (int pl = 0; pl < M.nplane; pl++) {
+        const float4 pn = M.p_plane[pl], pp = M.p_prm[pl];
+        for (int g0 = 0; g0 < M.ngeom; g0 += 64) {
+          const int g = g0 + lane;
+          bool a0 = false, a1 = false; v3 c0 = mk3(0.f, 0.f, 0.f), c1 = c0; float d0 = 0.f, d1 = 0.f, rad = 0.f, mu = 0.f;
+          if (g < M.ngeom) {
+            const int4 gi = M.g_info[g];
+            if (gi.x == FMJ_GEOM_SPHERE || gi.x == FMJ_GEOM_CAPSULE) {
+              const float4 gs = M.g_size[g], gp = M.g_pos[g], gq = M.g_quat[g];
+              const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+              const q4 bqq = {bq.x, bq.y, bq.z, bq.w};
+              const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+              rad = gs.x; mu = fmaxf(pp.x, gs.w);
+              v3 ax = mk3(0.f, 0.f, 0.f);
+              if (gi.x == FMJ_GEOM_CAPSULE) { const q4 gqq = {gq.x, gq.y, gq.z, gq.w}; ax = scl3(qrot(qmul(bqq, gqq), mk3(0.f, 0.f, 1.f)), gs.y); }
+              c0 = add3(cen, ax); c1 = sub3(cen, ax);
+              d0 = dot3(c0, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
+              d1 = dot3(c1, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
+              a0 = d0 < 0.f; a1 = gi.x == FMJ_GEOM_CAPSULE && d1 < 0.f;
+            }
+          }
+          const unsigned long long b0 = __ballot(a0), b1 = __ballot(a1);
+          const int s0 = ncon + __popcll(b0 & lt) + __popcll(b1 & lt), s1 = s0 + (a0 ? 1 : 0);
+          ncon += __popcll(b0) + __popcll(b1);
+          // frame: x = normal, t1 from (0,1,0) or (0,0,1) made orthogonal, t2 = n x t1 (mju_makeFrame)
+          v3 nrm = mk3(pn.x, pn.y, pn.z);
+          v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
+          t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
+          t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
+          const v3 t2 = cross(nrm, t1);
+#pragma unroll
+          for (int sgi = 0; sgi < 2; sgi++) {
+            const bool act = sgi ? a1 : a0; const int slot = sgi ? s1 : s0;
+            if (act && slot < M.max_contacts) {
+              const v3 cc = sgi ? c1 : c0; const float dd = sgi ? d1 : d0;
+              const v3 pos = sub3(cc, scl3(nrm, rad + 0.5f * dd));
+              float* ct = CT + slot * 16;
+              *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
+              *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
+              *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
+              *(float4*)(ct + 12) = make_float4(dd, mu, __int_as_float(g), pp.z);
+            }
+          }
+        }
+      }
+      if (ncon > M.max_contacts) { ncon = M.max_contacts; warn |= FMJ_WARN_CONTACTFULL; }
+      const int nefc = nlim + 4 * ncon;
+      WSYNC();
+      // (4) Jacobian rows.  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d =
+      //     cdof_lin + cdof_rot x (p - com) for the dofs on the body's chain.
+      for (int i = lane; i < nefc * nvs; i += 64) YJ[i] = 0.f;
+      WSYNC();
+      if (act_lo) { YJ[e_lo * nvs + lane] = 1.f;  float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
+      if (act_hi) { YJ[e_hi * nvs + lane] = -1.f; float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
+      {
+        const s6 cd = isd ? lds_get6(CD + lane * 8) : s6{mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
+        for (int c = 0; c < ncon; c++) {
+          const float* ct = CT + c * 16;
+          const float4 c0 = *(const float4*)(ct), c1 = *(const float4*)(ct + 4), c2 = *(const float4*)(ct + 8), c3 = *(const float4*)(ct + 12);
+          const int g = __float_as_int(c3.z);
+          const int last = M.g_info[g].z;                       // last dof on the contact body's chain
+          const bool on = isd && last >= 0 && lane <= last && last < lane + dsub;
+          const v3 jp = add3(cd.l, cross(cd.r, sub3(mk3(c0.x, c0.y, c0.z), com)));
+          const float jn = on ? dot3(jp, mk3(c0.w, c1.x, c1.y)) : 0.f;
+          const float j1 = on ? c3.y * dot3(jp, mk3(c1.z, c1.w, c2.x)) : 0.f;
+          const float j2 = on ? c3.y * dot3(jp, mk3(c2.y, c2.z, c2.w)) : 0.f;
+          if (isd) {
+            float* y = YJ + (nlim + 4 * c) * nvs + lane;
+            y[0] = jn + j1; y[nvs] = jn - j1; y[2 * nvs] = jn + j2; y[3 * nvs] = jn - j2;
+          }
+          if (lane < 4) { float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | c); ep[7] = c3.y; }
+        }
+      }
+      WSYNC();
+      // (5) per row (lane = row): R, aref (mj_makeImpedance / mj_referenceConstraint), b = J qacc_smooth - aref,
+      //     warm-start force from the previous qacc (mj_fwdConstraint)
+      for (int e = lane; e < nefc; e += 64) {
+        float* ep = EP + e * 8;
+        const int tid = __float_as_int(ep[6]);
+        const bool is_con = (tid & 0x40000000) != 0;
+        float sr0, sr1, si0, si1, si2, si3, si4, dapx;
+        const float mu = ep[7];
+        if (is_con) {
+          const float4 c3 = *(const float4*)(CT + (tid & 0xffff) * 16 + 12);
+          const int g = __float_as_int(c3.z);
+          const float4 a = M.g_sol0[g], b = M.g_sol1[g];
+          sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z;
+          const float tran = M.g_pos[g].w;                       // invweight0 of the body (+ 0 for the world plane)
+          dapx = tran + mu * mu * tran;
+        } else {
+          const float4 a = M.d_sol0[tid], b = M.d_sol1[tid];
+          sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z; dapx = b.w;
+        }
+        float R, kimp, bb;
+        row_params(sr0, sr1, si0, si1, si2, si3, si4, ep[0], ep[1], dapx, h, &R, &kimp, &bb);
+        float vel = 0.f, jxs = 0.f, jqw = 0.f;
+        const float* y = YJ + e * nvs;
+        for (int d = 0; d < nv; d++) { const float j = y[d]; vel = fmaf(j, QV[d], vel); jxs = fmaf(j, XS[d], jxs); jqw = fmaf(j, QW[d], jqw); }
+        const float aref = -bb * vel - kimp * (ep[0] - ep[1]);
+        ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
+      }
+      WSYNC();
+      // pyramidal: the 4 rows of a contact share R = 2 mu^2 R_first (mu scaled by 1/sqrt(impratio))
+      for (int e = lane; e < nefc; e += 64) {
+        float* ep = EP + e * 8;
+        const int tid = __float_as_int(ep[6]);
+        if (tid & 0x40000000) {
+          const int e0 = nlim + 4 * (tid & 0xffff);
+          const float mu = ep[7] * M.impratio_isqrt;
+          ep[2] = fmaxf(1e-15f, 2.f * mu * mu * EP[e0 * 8 + 5]);
+        }
+      }
+      WSYNC();
+      for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f; }
+      // (6) Y = J L^-1 (lane = row): y_a -= L[i][a] y_i for every dof i (leaves first) and ancestor a
+      for (int i = nv - 1; i >= 1; i--) {
+        const float di = DI[i];
+        const int depi = __builtin_amdgcn_readlane(ddepth, i);
+        for (int e = lane; e < nefc; e += 64) {
+          float* y = YJ + e * nvs;
+          const float yi = y[i];
+          int a = i;
+          for (int dd = depi - 1; dd >= 0; dd--) {
+            a = __builtin_amdgcn_readlane(dparent, a);          // uniform parent walk: ancestor at depth dd
+            y[a] = fmaf(-HM[i * RS + dd] * di, yi, y[a]);
+          }
+        }
+      }
+      WSYNC();
+      // (7) diagA, w0 = D^-1 Y' f, dual cost of the warm start; zero it if it is worse than f = 0
+      for (int e = lane; e < nefc; e += 64) {
+        const float* y = YJ + e * nvs; float s = 0.f;
+        for (int d = 0; d < nv; d++) s = fmaf(y[d] * y[d], DI[d], s);
+        const float da = s + EP[e * 8 + 2];
+        EP[e * 8 + 5] = da; EP[e * 8] = 1.0f / da;                   // pos is no longer needed: slot 0 = 1/A_ee
+      }
+      float w = 0.f;
+      if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], EP[e * 8 + 4], w); w *= dinv_m; WW[lane] = w; }
+      WSYNC();
+      {
+        float cost = 0.f;
+        for (int e = lane; e < nefc; e += 64) {
+          const float* y = YJ + e * nvs; const float* ep = EP + e * 8; float af = ep[2] * ep[4];
+          for (int d = 0; d < nv; d++) af = fmaf(y[d], WW[d], af);
+          cost += ep[4] * (0.5f * af + ep[3]);
+        }
+        cost = wave_sum_fast(cost);
+        if (cost > 0.f) { w = 0.f; for (int e = lane; e < nefc; e += 64) EP[e * 8 + 4] = 0.f; }
+      }
+      WSYNC();
+      // (8) PGS (mj_solPGS): rows in order, f_e <- max(0, f_e - res/A_ee), revert a row if its cost change > 1e-10
+      for (int itp = 0; itp < M.solver_iterations; itp++) {
+        float improvement = 0.f;
+        for (int e = 0; e < nefc; e++) {
+          const float4 e0 = *(const float4*)(EP + e * 8);          // 1/A_ee, aref, R, b
+          const float2 e1 = *(const float2*)(EP + e * 8 + 4);      // force, diagA
+          const float y = isd ? YJ[e * nvs + lane] : 0.f;
+          const float res = e0.w + wave_sum_fast(y * w) + e0.z * e1.x;
+          float fnew = fmaxf(0.f, e1.x - res * e0.x);
+          float delta = fnew - e1.x;
+          float change = 0.5f * delta * delta * e1.y + delta * res;
+          if (change > 1e-10f) { fnew = e1.x; delta = 0.f; change = 0.f; }
+          improvement -= change;
+          w = fmaf(delta * dinv_m, y, w);
+          if (lane == 0) EP[e * 8 + 4] = fnew;
+        }
+        if (improvement * M.pgs_scale < M.solver_tolerance) break;
+      }
+      WSYNC();
+      // (9) qfrc_constraint = J' f = L'(Y' f) ; qacc = qacc_smooth + L^-1 w  (saved as next step's warm start)
+      {
+        const float u = isd ? w / dinv_m : 0.f;                      // (Y' f)_d
+        float q = u;
+        for (int i = nv - 1; i >= 1; i--) {
+          const float ui = bcast(u, i) * bcast(dinv_m, i);
+          const bool anc = lane < i && i < lane + dsub;
+          q = fmaf(anc ? HM[i * RS + ddepth] : 0.f, ui, q);
+        }
+        qfrc_c = q;
+        float xa = w;
+        const int dli = isd ? lane : 0;
+        for (int j = 0; j < nv - 1; j++) {
+          const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
+          const bool desc = isd && j < lane && lane < j + subj;
+          xa = fmaf(desc ? -HM[dli * RS + depj] * dinv_m : 0.f, bcast(xa, j), xa);
+        }
+        if (isd) { const float qa = xs + xa; QW[lane] = qa; if (!(fabsf(qa) <= 1e10f)) warn |= FMJ_WARN_BADQACC; }
+      }
+      // (10) sensors: joint limit force; contact forces in the contact frame (mj_contactForce, pyramidal)
+      {
+        float lf = 0.f;
+        if (act_lo) lf += EP[e_lo * 8 + 4];
+        if (act_hi) lf += EP[e_hi * 8 + 4];
+        cy_limfrc = lf * A.inv_torques;
+        if (last && d_scalar) A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z + 2] = lf;
+        if (last) {
+          for (int c = lane; c < ncon; c += 64) {
+            const float* ep = EP + (nlim + 4 * c) * 8;
+            const float f0 = ep[4], f1 = ep[12], f2 = ep[20], f3 = ep[28], mu = ep[7];
+            const float* ct = CT + c * 16;
+            float* o = A.contact + ((size_t)env * M.max_contacts + c) * 16;
+            *(float4*)(o) = *(const float4*)(ct); *(float4*)(o + 4) = *(const float4*)(ct + 4); *(float4*)(o + 8) = *(const float4*)(ct + 8);
+            *(float4*)(o + 12) = make_float4(f0 + f1 + f2 + f3, mu * (f0 - f1), mu * (f2 - f3), ct[14]);
+          }
+          if (lane == 0) A.ncon[env] = ncon;
+        }
+      }
+      WSYNC();
+    }
     // ---- L + X: sparse L'DL of H = M + diag(armature + h*damping) and the solve H qacc = qfrc_smooth
     float my_qacc;
     {
@@ -880,7 +1210,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
       float dinv_mine;
       ldl_factor<MAXD>(HR, lane, isd, ddepth, dsub, nv, r, dinv_mine);
       STAMP(9);   // L
-      my_qacc = ldl_solve<MAXD>(HR, qfrc, lane, isd, ddepth, dsub, nv, dinv_mine);
+      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine);
     }
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
@@ -896,7 +1226,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
         QP[d_qadr] = pre_q + hstep * nvel;
         if (last) {
           float* s = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z;   // jointpos, jointvel, jointlimitfrc
-          s[0] = pre_q; s[1] = pre_qd; s[2] = 0.f;
+          s[0] = pre_q; s[1] = pre_qd; if (!CONS) s[2] = 0.f;
         }
       }
       if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
@@ -922,6 +1252,7 @@ __global__ void __launch_bounds__(64, 4) fmj_step_kernel(const DevModel M, const
   for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
   for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
   if (A.qacc) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
+  if (CONS) for (int i = lane; i < nv; i += 64) A.qacc_warmstart[(size_t)env * nv + i] = QW[i];
 #ifdef FMJ_STAMPS
   if (env == 0 && lane == 0 && A.qacc) {
 #pragma unroll
@@ -1007,6 +1338,50 @@ __global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, 
   }
 }
 
+
+// cycontacts2data (reference sensors.pyx:140-190): lane = contact sensor row; every contact of the env is
+// tested against the 4 keys (g1,g2,-1) (g2,g1,+1) (g1,-1,-1) (g2,-1,+1) of geompair2data (sensors.pyx:163-169).
+__global__ void __launch_bounds__(64) fmj_contacts2data_kernel(const DevModel M, const StepArgs A, const int n_rows,
+                                                                const int* geom_sensor, const int n_pairs, const int* pairs) {
+  const int env = blockIdx.x;
+  const int nc = A.ncon[env];
+  const float* C = A.contact + (size_t)env * M.max_contacts * 16;
+  for (int row = threadIdx.x; row < n_rows; row += 64) {
+    float acc[12]; float norm_sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < 12; k++) acc[k] = 0.f;
+    for (int c = 0; c < nc; c++) {
+      const float* ct = C + c * 16;
+      const int g2 = __float_as_int(ct[15]), g1 = -2;      // geom1 = the plane: not a sensor key in this subset
+      (void)g1;
+      for (int key = 0; key < 2; key++) {
+        int sign = 0;
+        if (key == 0) { if (geom_sensor[g2] == row) sign = +1; }                 // (g2, -1) -> +1
+        else { for (int p = 0; p < n_pairs; p++) if (pairs[3 * p + 2] == row && pairs[3 * p + 1] == g2) sign = -1; }   // (g1, g2) -> -1
+        if (!sign) continue;
+        float tot[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {                                            // store_forces, sensors.pyx:33-52
+          const float reaction = sign * ct[12] * ct[3 + i];
+          const float friction = sign * ct[13] * ct[6 + i] + sign * ct[14] * ct[9 + i];
+          tot[i] = reaction + friction;
+          acc[FMJ_CONTACT_REACTION + i] += reaction; acc[FMJ_CONTACT_FRICTION + i] += friction; acc[FMJ_CONTACT_TOTAL + i] += tot[i];
+        }
+        const float nrm = sqrtf(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] += nrm * ct[i];
+        norm_sum += nrm;
+      }
+    }
+    if (norm_sum > 0.f) { for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] /= norm_sum; }     // sensors.pyx:85-88
+    float* out = A.contacts_rows + ((size_t)env * n_rows + row) * FMJ_CONTACT_SIZE;
+#pragma unroll
+    for (int k = 0; k < 9; k++) out[k] = acc[k] * A.inv_newtons;                                       // :99-107
+#pragma unroll
+    for (int k = 9; k < 12; k++) out[k] = acc[k] * A.inv_meters;                                       // :108-110
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // host side
 
@@ -1027,22 +1402,27 @@ static float ibits(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 // pick the instantiation whose register row length matches the model's dof-chain length
 typedef void (*step_kernel_t)(const DevModel, const StepArgs);
-template <bool FUSED>
+template <bool FUSED, bool CONS>
 static step_kernel_t pick_step_kernel(int rs) {
   switch (rs) {
-    case 4: return fmj_step_kernel<FUSED, 4>;
-    case 8: return fmj_step_kernel<FUSED, 8>;
-    case 12: return fmj_step_kernel<FUSED, 12>;
-    case 16: return fmj_step_kernel<FUSED, 16>;
-    case 20: return fmj_step_kernel<FUSED, 20>;
-    case 24: return fmj_step_kernel<FUSED, 24>;
-    case 28: return fmj_step_kernel<FUSED, 28>;
-    default: return fmj_step_kernel<FUSED, 32>;
+    case 4: return fmj_step_kernel<FUSED, 4, CONS>;
+    case 8: return fmj_step_kernel<FUSED, 8, CONS>;
+    case 12: return fmj_step_kernel<FUSED, 12, CONS>;
+    case 16: return fmj_step_kernel<FUSED, 16, CONS>;
+    case 20: return fmj_step_kernel<FUSED, 20, CONS>;
+    case 24: return fmj_step_kernel<FUSED, 24, CONS>;
+    case 28: return fmj_step_kernel<FUSED, 28, CONS>;
+    default: return fmj_step_kernel<FUSED, 32, CONS>;
   }
 }
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
+  if (c->dm.cons) return fused ? pick_step_kernel<true, true>(c->dm.rs) : pick_step_kernel<false, true>(c->dm.rs);
+  return fused ? pick_step_kernel<true, false>(c->dm.rs) : pick_step_kernel<false, false>(c->dm.rs);
+}
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
-  step_kernel_t k = fused ? pick_step_kernel<true>(c->dm.rs) : pick_step_kernel<false>(c->dm.rs);
-  hipLaunchKernelGGL(k, dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
+  if (c->dm.cons && (!A.qacc_warmstart || !A.contact || !A.ncon))
+    return set_err(FMJ_ERR_ARG, "fmj_data: qacc_warmstart, contact and ncon are required for models with limits / contacts");
+  hipLaunchKernelGGL(pick_kernel(c, fused), dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
   return FMJ_OK;
@@ -1066,8 +1446,16 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
   const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
   if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
-  if (m->ngeom > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: collision geoms / contacts are not in the HIP path yet");
-  for (int j = 0; j < nj; j++) if (m->jnt_limited[j]) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: joint limits are not in the HIP path yet");
+  int any_limit = 0, nplane = 0;
+  for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE) any_limit = 1;
+  for (int g = 0; g < m->ngeom; g++) {
+    int t = m->geom_type[g];
+    if (t == FMJ_GEOM_PLANE) { if (m->geom_bodyid[g] != 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: planes must be attached to the world body"); nplane++; }
+    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule geoms are in the HIP path");
+    else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
+  }
+  const int cons = any_limit || (nplane > 0 && m->ngeom > nplane);
+  if (cons && m->ngeom > nplane && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
   if (m->body_parentid[1] != 0) return set_err(FMJ_ERR_ARG, "fmj_create: body 1 must be the root (parent = world)");
   std::vector<int> bdepth(nb, 0), subsize(nb, 1);
@@ -1224,11 +1612,63 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->d_b_info2 = (int4*)D.b_info2; c->d_d_info = (int4*)D.d_info;
   std::vector<float4> empty4(1, f4(0, 0, 0, 0));
   UP(empty4, s_c0); UP(empty4, s_c1); UP(empty4, s_c2);
-  LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride);
+  // ---- constraint tables
+  D.cons = cons; D.ngeom = m->ngeom; D.nplane = nplane; D.nvs = nv | 1;
+  D.max_contacts = cons ? (m->max_contacts > 0 ? m->max_contacts : 1) : 0;
+  {
+    int nlimj = 0; for (int j = 0; j < nj; j++) nlimj += (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE);
+    D.maxefc = cons ? nlimj + 4 * D.max_contacts : 0;
+  }
+  D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
+  D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
+  D.pgs_scale = (float)(1.0 / ((m->meaninertia > 0 ? m->meaninertia : 1.0) * (nv > 1 ? nv : 1)));
+  std::vector<float> m_arm(nMpad, 0.f);
+  { int ee = 0; for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { if (i == j) m_arm[ee] = (float)m->dof_armature[i]; ee++; } }
+  std::vector<int> d_parent(64, -1);
+  for (int d = 0; d < nv; d++) d_parent[d] = m->dof_parentid[d];
+  std::vector<int4> g_info(m->ngeom ? m->ngeom : 1); std::vector<float4> g_size(g_info.size()), g_pos(g_info.size()), g_quat(g_info.size()), g_sol0(g_info.size()), g_sol1(g_info.size());
+  std::vector<float4> p_plane(nplane ? nplane : 1), p_prm(nplane ? nplane : 1);
+  std::vector<float4> d_lim(64, f4(0, 0, 0, 0)), d_sol0(64, f4(0.02, 1, 0.9, 0.95)), d_sol1(64, f4(0.001, 0.5, 2, 0));
+  if (cons) {
+    int ip = 0;
+    for (int g = 0; g < m->ngeom; g++) {
+      int b = m->geom_bodyid[g];
+      int last = -1;
+      for (int a = b; a >= 1 && last < 0; a = m->body_parentid[a]) if (m->body_dofnum[a] > 0) last = m->body_dofadr[a] + m->body_dofnum[a] - 1;
+      g_info[g] = make_int4(m->geom_type[g], b, last, 0);
+      g_size[g] = f4(m->geom_size[3 * g], m->geom_size[3 * g + 1], m->geom_size[3 * g + 2], m->geom_friction[3 * g]);
+      g_pos[g] = f4(m->geom_pos[3 * g], m->geom_pos[3 * g + 1], m->geom_pos[3 * g + 2], m->body_invweight0[2 * b]);
+      g_quat[g] = f4(m->geom_quat[4 * g], m->geom_quat[4 * g + 1], m->geom_quat[4 * g + 2], m->geom_quat[4 * g + 3]);
+      g_sol0[g] = f4(m->geom_solref[2 * g], m->geom_solref[2 * g + 1], m->geom_solimp[5 * g], m->geom_solimp[5 * g + 1]);
+      g_sol1[g] = f4(m->geom_solimp[5 * g + 2], m->geom_solimp[5 * g + 3], m->geom_solimp[5 * g + 4], 0);
+      if (m->geom_type[g] == FMJ_GEOM_PLANE) {
+        // world-attached plane: normal = z axis of the geom frame, point = geom_pos
+        const double* q = m->geom_quat + 4 * g; const double* p = m->geom_pos + 3 * g;
+        double nx = 2 * (q[1] * q[3] + q[0] * q[2]), ny = 2 * (q[2] * q[3] - q[0] * q[1]), nz = q[0] * q[0] - q[1] * q[1] - q[2] * q[2] + q[3] * q[3];
+        double nn = sqrt(nx * nx + ny * ny + nz * nz); nx /= nn; ny /= nn; nz /= nn;
+        p_plane[ip] = f4(nx, ny, nz, nx * p[0] + ny * p[1] + nz * p[2]);
+        p_prm[ip] = make_float4((float)m->geom_friction[3 * g], 0.f, ibits(g), 0.f);
+        ip++;
+      }
+    }
+    for (int j = 0; j < nj; j++) {
+      if (m->jnt_type[j] == FMJ_JNT_FREE) continue;
+      int d = m->jnt_dofadr[j];
+      d_lim[d] = f4(m->jnt_limited[j] ? 1 : 0, m->jnt_range[2 * j], m->jnt_range[2 * j + 1], m->jnt_margin[j]);
+      d_sol0[d] = f4(m->jnt_solref[2 * j], m->jnt_solref[2 * j + 1], m->jnt_solimp[5 * j], m->jnt_solimp[5 * j + 1]);
+      d_sol1[d] = f4(m->jnt_solimp[5 * j + 2], m->jnt_solimp[5 * j + 3], m->jnt_solimp[5 * j + 4], m->dof_invweight0[d]);
+    }
+  }
+  UP(m_arm, m_arm); UP(d_parent, d_parent); UP(g_info, g_info); UP(g_size, g_size); UP(g_pos, g_pos); UP(g_quat, g_quat);
+  UP(g_sol0, g_sol0); UP(g_sol1, g_sol1); UP(p_plane, p_plane); UP(p_prm, p_prm); UP(d_lim, d_lim); UP(d_sol0, d_sol0); UP(d_sol1, d_sol1);
+  c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
+  c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
+  for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
+  LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
   c->lds_bytes = (size_t)L.total * sizeof(float);
   if (c->lds_bytes > 64 * 1024) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)pick_step_kernel<true>(D.rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
-    hipError_t e2 = hipFuncSetAttribute((const void*)pick_step_kernel<false>(D.rs), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    hipError_t e1 = hipFuncSetAttribute((const void*)pick_kernel(c, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
+    hipError_t e2 = hipFuncSetAttribute((const void*)pick_kernel(c, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     if (e1 != hipSuccess || e2 != hipSuccess) { fmj_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_create: LDS request too large"); }
   }
   *out = c;
@@ -1305,6 +1745,7 @@ static int fill_data(const fmj_ctx* c, const fmj_data* d, StepArgs* A, bool need
   A->qpos = d->qpos; A->qvel = d->qvel; A->ctrl = d->ctrl; A->qpos_spring = d->qpos_spring; A->xfrc_applied = d->xfrc_applied;
   A->xpos = d->xpos; A->xquat = d->xquat; A->xipos = d->xipos; A->sensordata = d->sensordata; A->qacc = d->qacc;
   A->time = d->time; A->status = d->status; A->n_envs = c->n_envs;
+  A->qacc_warmstart = d->qacc_warmstart; A->contact = d->contact; A->ncon = d->ncon;
   A->inv_meters = A->inv_velocity = A->inv_angvel = A->inv_torques = A->newtons = A->torques = 1.0f;
   A->buffer_size = 1;
   return FMJ_OK;
@@ -1312,7 +1753,7 @@ static int fill_data(const fmj_ctx* c, const fmj_data* d, StepArgs* A, bool need
 
 static void fill_units(StepArgs* A, const fmj_units* u) {
   A->inv_meters = 1.0f / u->meters; A->inv_velocity = 1.0f / u->velocity; A->inv_angvel = 1.0f / u->angular_velocity;
-  A->inv_torques = 1.0f / u->torques; A->newtons = u->newtons; A->torques = u->torques;
+  A->inv_torques = 1.0f / u->torques; A->newtons = u->newtons; A->torques = u->torques; A->inv_newtons = 1.0f / u->newtons;
 }
 static void fill_water(StepArgs* A, const fmj_water* w) {
   A->surface = w->surface; A->viscosity = w->viscosity; A->wvx = w->velocity[0]; A->wvy = w->velocity[1]; A->wvz = w->velocity[2];
@@ -1386,6 +1827,37 @@ int fmj_physics2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const 
   HIP_TRY(hipMemcpyAsync(d_lb, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
   HIP_TRY(hipMemcpyAsync(d_jd, jd.data(), jd.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
   hipLaunchKernelGGL(fmj_physics2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)links_only, (const int*)d_lb, (const int*)d_jd);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_set_contact_maps(fmj_ctx* c, int32_t n_rows, const int32_t* geom_sensor, int32_t n_pairs, const int32_t* pairs) {
+  if (!c || n_rows < 0 || n_pairs < 0 || (c->ngeom && !geom_sensor) || (n_pairs && !pairs)) return set_err(FMJ_ERR_ARG, "fmj_set_contact_maps: NULL argument");
+  HIP_TRY(hipSetDevice(c->device));
+  for (int g = 0; g < c->ngeom; g++) {
+    if (geom_sensor[g] >= n_rows) return set_err(FMJ_ERR_ARG, "fmj_set_contact_maps: row out of range");
+    c->geom_sensor[g] = geom_sensor[g];
+  }
+  for (int p = 0; p < n_pairs; p++)
+    if (pairs[3 * p] < 0 || pairs[3 * p] >= c->ngeom || pairs[3 * p + 1] < 0 || pairs[3 * p + 1] >= c->ngeom || pairs[3 * p + 2] < 0 || pairs[3 * p + 2] >= n_rows)
+      return set_err(FMJ_ERR_ARG, "fmj_set_contact_maps: pair out of range");
+  std::vector<int> gs(c->geom_sensor), pr(pairs, pairs + 3 * n_pairs);
+  const int* dg = nullptr; const int* dp = nullptr;
+  int rc;
+  if ((rc = upload(c, gs, &dg)) || (rc = upload(c, pr, &dp))) return rc;
+  c->d_geom_sensor = (int*)dg; c->d_pairs = (int*)dp; c->n_pairs = n_pairs; c->n_contact_rows = n_rows;
+  return FMJ_OK;
+}
+
+int fmj_contacts2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const fmj_units* units, void* stream) {
+  if (!c || !d || !rows || !units || !rows->contacts || !d->contact || !d->ncon) return set_err(FMJ_ERR_ARG, "fmj_contacts2data: NULL argument");
+  if (!c->d_geom_sensor) return set_err(FMJ_ERR_ARG, "fmj_contacts2data: call fmj_set_contact_maps first");
+  StepArgs A; memset(&A, 0, sizeof A);
+  A.n_envs = c->n_envs; A.contact = d->contact; A.ncon = d->ncon; A.contacts_rows = rows->contacts;
+  fill_units(&A, units);
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_contacts2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, c->n_contact_rows,
+                     (const int*)c->d_geom_sensor, c->n_pairs, (const int*)c->d_pairs);
   HIP_TRY(hipGetLastError());
   return FMJ_OK;
 }

@@ -221,7 +221,7 @@ _CMODEL_FIELDS = (
         [(n, _D) for n in ('geom_size', 'geom_pos', 'geom_quat', 'geom_friction', 'geom_solref', 'geom_solimp',
                            'body_invweight0')] +
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
-         ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double)]
+         ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)]
 )
 
 
@@ -468,6 +468,7 @@ class Model:
         c.gravity = (ctypes.c_double*3)(*self.gravity)
         c.impratio = self.impratio
         c.solver_tolerance = self.solver_tolerance
+        c.meaninertia = self.meaninertia
         for n in _INT_FIELDS:
             a = np.ascontiguousarray(getattr(self, n), np.int32)
             if a.size == 0:

@@ -56,6 +56,11 @@ class BatchedPhysics:
             qpos=z(n, m.nq), qvel=z(n, m.nv), ctrl=z(n, m.nu), qpos_spring=z(n, m.nq),
             xfrc_applied=z(n, m.nbody, 6), xpos=z(n, m.nbody, 3), xquat=z(n, m.nbody, 4), xipos=z(n, m.nbody, 3),
             sensordata=z(n, m.nsensordata), qacc=z(n, m.nv), time=z(n), status=z(n, dtype=torch.int32))
+        self.has_constraints = bool(np.any(m.jnt_limited)) or m.ngeom > 0
+        self.max_contacts = max(int(m.max_contacts), 1)
+        self.data.qacc_warmstart = z(n, m.nv)
+        self.data.contact = z(n, self.max_contacts, 16)
+        self.data.ncon = z(n, dtype=torch.int32)
         self.data.xquat[:, :, 0] = 1.0
         self.data.qpos_spring[:] = torch.as_tensor(m.qpos_spring, dtype=torch.float32)
         self.links_body = np.arange(1, m.nbody, dtype=np.int32)
@@ -79,6 +84,7 @@ class BatchedPhysics:
         c.xpos, c.xquat, c.xipos = d.xpos.data_ptr(), d.xquat.data_ptr(), d.xipos.data_ptr()
         c.sensordata, c.qacc, c.time, c.status = (d.sensordata.data_ptr(), d.qacc.data_ptr(), d.time.data_ptr(),
                                                   d.status.data_ptr())
+        c.qacc_warmstart, c.contact, c.ncon = d.qacc_warmstart.data_ptr(), d.contact.data_ptr(), d.ncon.data_ptr()
         return c
 
     # ---- dm_control Physics surface -----------------------------------------------------------------
@@ -89,7 +95,7 @@ class BatchedPhysics:
         d.qpos[:] = torch.as_tensor(m.key_qpos, dtype=torch.float32)
         d.qvel[:] = torch.as_tensor(m.key_qvel, dtype=torch.float32)
         d.ctrl.zero_(); d.xfrc_applied.zero_(); d.time.zero_(); d.status.zero_(); d.qacc.zero_()
-        d.sensordata.zero_()
+        d.sensordata.zero_(); d.qacc_warmstart.zero_(); d.contact.zero_(); d.ncon.zero_()
         self.forward(disable_actuation=True)
 
     def forward(self, disable_actuation: bool = False):
@@ -133,6 +139,15 @@ class BatchedPhysics:
         b = [np.ascontiguousarray(x, np.float64) for x in (coefficients, masses, heights, densities)]
         _lib.check(self._lib.fmj_set_swimming(self._ctx, len(a[0]), *[x.ctypes.data_as(I) for x in a],
                                               *[x.ctypes.data_as(D) for x in b]))
+
+    def set_contact_maps(self, n_rows, geom_sensor, pairs=()):
+        """geompair2data (reference physics.py:360-382): geom -> contact sensor row for keys (geom, -1), plus explicit
+        (geom1, geom2, row) pairs."""
+        I = ctypes.POINTER(ctypes.c_int32)
+        gs = np.ascontiguousarray(geom_sensor, np.int32)
+        pr = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 3))
+        _lib.check(self._lib.fmj_set_contact_maps(self._ctx, int(n_rows), gs.ctypes.data_as(I), len(pr),
+                                                  pr.ctypes.data_as(I) if len(pr) else None))
 
     def kernel_info(self):
         lds, thr = ctypes.c_int32(), ctypes.c_int32()

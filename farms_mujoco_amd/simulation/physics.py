@@ -36,6 +36,18 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     sensor_maps['datalinks2xfrc'] = links_body
     sensor_maps['data2xfrc'] = np.array([m.body_names.index(n) for n in sensor_data.xfrc.names], np.int32)
     physics.set_readout_maps(links_body, joints_jnt)
+    # Contacts (reference physics.py:360-382): pairs (body, '') -> every geom of that body keys (geom, -1)
+    contacts_pairs = list(sensor_data.contacts.names)
+    geom_sensor = -np.ones(max(m.ngeom, 1), np.int32)
+    geompair2data = {}
+    for g in range(m.ngeom):
+        key = (m.body_names[m.geom_bodyid[g]], '')
+        if key in contacts_pairs:
+            geom_sensor[g] = contacts_pairs.index(key)
+            geompair2data[(g, -1)] = contacts_pairs.index(key)
+    sensor_maps['geompair2data'] = geompair2data
+    if contacts_pairs:
+        physics.set_contact_maps(len(contacts_pairs), geom_sensor)
     return sensor_maps
 
 
@@ -49,3 +61,7 @@ def physics2data(physics, iteration, data, maps, units, links_only=False):
     _lib.check(physics._lib.fmj_physics2data(physics._ctx, ctypes.byref(c), ctypes.byref(rows), ctypes.byref(u),
                                              int(links_only),
                                              ctypes.c_void_p(torch.cuda.current_stream(physics.device).cuda_stream)))
+    if not links_only and data.sensors.contacts.names:
+        from ..sensors.sensors import cycontacts2data
+        cycontacts2data(physics=physics, iteration=iteration, data=data.sensors.contacts,
+                        geompair2data=maps['sensors'].get('geompair2data', {}), meters=units.meters, newtons=units.newtons)

@@ -143,6 +143,7 @@ typedef struct fmj_model {
   int32_t max_contacts;         /* per environment */
   double impratio;
   double solver_tolerance;
+  double meaninertia;           /* mjModel.stat.meaninertia: mean diagonal of M at qpos0 (PGS termination scale) */
 } fmj_model;
 
 /* ---- per-env device buffers for the physics step -------------------------------------------
@@ -162,6 +163,11 @@ typedef struct fmj_data {
   float* qacc;               /* [n_envs,nv] may be NULL */
   float* time;               /* [n_envs]   may be NULL */
   int32_t* status;           /* [n_envs]   warning bits, OR-accumulated                   */
+  /* constraint path: required when the model has joint limits or collision geoms, else may be NULL */
+  float* qacc_warmstart;     /* [n_envs,nv] in/out: qacc of the previous step (PGS warm start)  */
+  float* contact;            /* [n_envs,max_contacts,16] out: pos(3) frame(9: normal,t1,t2) force(3: normal,t1,t2
+                                in the contact frame, what mj_contactForce returns) geom id (as float)   */
+  int32_t* ncon;             /* [n_envs] out: active contacts of the last forward pass              */
 } fmj_data;
 
 /* sensordata layout, in the order reference mjcf.py:950-1002 adds the sensors */
@@ -249,6 +255,18 @@ int fmj_drag(fmj_ctx* ctx, const fmj_rows* rows, const fmj_water* water,
  * physics.py:527-545): mjData fields -> AnimatData rows with unit scaling. */
 int fmj_physics2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows,
                      const fmj_units* units, int32_t links_only, void* hip_stream);
+
+/* Contact sensors: map of collision geoms / geom pairs to AnimatData contact rows
+ * (geompair2data, reference physics.py:360-382).  geom_sensor[g] = row of key (g, -1) or -1;
+ * pairs = n_pairs x (geom1, geom2, row).  HOST pointers, copied. */
+int fmj_set_contact_maps(fmj_ctx* ctx, int32_t n_contact_sensors, const int32_t* geom_sensor,
+                         int32_t n_pairs, const int32_t* pairs);
+
+/* cycontacts2data(physics, iteration, data, geompair2data, meters, newtons) (reference
+ * sensors.pyx:140-190): contact list of the last forward pass -> rows->contacts (row is
+ * overwritten: reaction, friction, total force, force-weighted position). */
+int fmj_contacts2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows, const fmj_units* units,
+                      void* hip_stream);
 
 /* Fused loop: for s in [0,n_steps): physics2data(row (it0+s)%buffer) -> drag -> xfrc_applied
  * -> ctrl -> mj_step, state and derived fields resident in LDS between steps
