@@ -53,50 +53,40 @@ struct DevModel {
   int n_links, n_joints, n_xfrc, ns;
   int anc_stride;     // bytes per chain row (multiple of 4)
   float h, gx, gy, gz, mtot_inv;
-  // per body [64]
-  const float4* b_pos_mass;   // body_pos xyz, mass
-  const float4* b_quat;
-  const float4* b_ipos;
-  const float4* b_iquat;
-  const float4* b_inertia;
-  const float4* j_axis_q0;    // joint axis xyz, qpos0 of the joint coordinate
-  const float4* j_pos_k;      // joint pos xyz, stiffness
-  const int4* b_info;         // parent, jnt type (-1 none), qposadr, dofadr
-  const int4* b_info2;        // depth (chain length-1), subtree size, link row (-1), swim slot (-1)
+  const float4* btab;         // [64][BT_STRIDE]
+  const float4* dtab;         // [64][DT_STRIDE]
+  const float4* atab;         // [nu][AT_STRIDE]
+  const float4* mtab;         // [nMpad] (entry bits i | j<<6 | depth<<12 | body(i)<<18 | valid<<24, armature + h*damping, armature, -)
+  const float4* stab;         // [ns][ST_STRIDE]
+  const float4* gtab;         // [ngeom][GT_STRIDE]
+  const float4* ptab;         // [nplane][PT_STRIDE]
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
-  // per dof [64]
-  const int4* d_info;         // body, depth, subtree size (dofs), joint row (-1)
-  const float4* d_prm;        // armature, damping, qposadr(as float bits), is_hinge_or_slide
-  const int4* d_act;          // first actuator, count (actuators sorted by dof), joint-sensor slot, -
-  // actuators [nu] sorted by dof; a_src = original actuator index
-  const float4* a_prm;        // gain, bias0, bias1, bias2
-  const float4* a_lim;        // ctrl lo, ctrl hi, force lo, force hi (+-FLT_MAX when unlimited)
-  const int* a_src;
-  // M entries [nMpad]: i | j<<6 | depth<<12 | body(i)<<18 | valid<<24 ; m_add = armature + h*damping on the diagonal
-  const uint32_t* m_tab;
-  const float* m_add;
-  // swimming [ns]: coeff(6), mass, height, density -> 3 float4
-  const float4* s_c0;         // clin xyz, mass
-  const float4* s_c1;         // cang xyz, height
-  const float4* s_c2;         // density, links_index, xfrc_index, body
   // ---- constraint path (joint limits, plane contacts, pyramidal cone, PGS) ----
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
-  const int4* g_info;         // [ngeom] type, body, last dof on the body's chain (-1 none), -
-  const float4* g_size;       // [ngeom] size xyz, friction[0]
-  const float4* g_pos;        // [ngeom] pos xyz, translational invweight0 of the body
-  const float4* g_quat;       // [ngeom]
-  const float4* g_sol0;       // [ngeom] solref0, solref1, solimp0, solimp1
-  const float4* g_sol1;       // [ngeom] solimp2, solimp3, solimp4, -
-  const float4* p_plane;      // [nplane] unit normal xyz, offset n.p0  (static planes on the world body)
-  const float4* p_prm;        // [nplane] friction[0], translational invweight0 (0), geom id bits, -
-  const float4* d_lim;        // [nv] limited flag, range lo, range hi, margin   (hinge/slide dofs)
-  const float4* d_sol0;       // [nv] solref0, solref1, solimp0, solimp1
-  const float4* d_sol1;       // [nv] solimp2, solimp3, solimp4, dof_invweight0
-  const float* m_arm;         // [nMpad] armature on the diagonal entries (M itself, without h*damping)
-  const int* d_parent;        // [64] dof_parentid
 };
+
+
+// packed model tables (one pointer per family keeps kernel-argument SGPR pressure down)
+#define BT_STRIDE 9    // per body: pos_mass, quat, ipos, iquat, inertia, axis_q0, jpos_k, info(int4), info2(int4)
+#define DT_STRIDE 6    // per dof: info(int4), prm, act(int4: first, count, joint-sensor slot, dof parent), lim, sol0, sol1
+#define AT_STRIDE 3    // per actuator (sorted by dof): prm, lim, (source index bits, -, -, -)
+#define ST_STRIDE 3    // per swimming link: c0, c1, c2
+#define GT_STRIDE 6    // per geom: info(int4), size, pos, quat, sol0, sol1
+#define PT_STRIDE 2    // per plane: plane, prm
+__device__ __forceinline__ unsigned __float_as_uint_(float f) { return (unsigned)__float_as_int(f); }
+__device__ __forceinline__ int4 as_int4(float4 v) { return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)); }
+#define BTAB(b, k) (M.btab[(unsigned)(b) * BT_STRIDE + (k)])
+#define BTABI(b, k) as_int4(BTAB(b, k))
+#define DTAB(d, k) (M.dtab[(unsigned)(d) * DT_STRIDE + (k)])
+#define DTABI(d, k) as_int4(DTAB(d, k))
+#define ATAB(a, k) (M.atab[(unsigned)(a) * AT_STRIDE + (k)])
+#define MTAB(e) (M.mtab[(unsigned)(e)])
+#define STAB(i, k) (M.stab[(unsigned)(i) * ST_STRIDE + (k)])
+#define GTAB(g, k) (M.gtab[(unsigned)(g) * GT_STRIDE + (k)])
+#define GTABI(g, k) as_int4(GTAB(g, k))
+#define PTAB(p, k) (M.ptab[(unsigned)(p) * PT_STRIDE + (k)])
 
 struct StepArgs {
   float* qpos; float* qvel; const float* ctrl; const float* qpos_spring; const float* xfrc_applied;
@@ -122,7 +112,7 @@ struct fmj_ctx {
   std::vector<int> body_link_row, dof_joint_row, body_swim;
   std::vector<int> h_b_info2;     // mutable table mirror
   std::vector<int> h_d_info;
-  int4* d_b_info2; int4* d_d_info;
+  float4* d_btab; float4* d_dtab; std::vector<float4> h_btab, h_dtab;
   int nbody, nv, nu, njnt;
   std::vector<int> jnt_dofadr, jnt_type;
   int ngeom, n_contact_rows, n_pairs; std::vector<int> geom_sensor, geom_is_plane; int* d_geom_sensor; int* d_pairs;
@@ -490,7 +480,7 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 #pragma unroll
     for (int k = 0; k < 6; k++) xf[k] = 0.f;
     if (isb && swim_slot >= 0) {
-      const float4 s0 = M.s_c0[swim_slot], s1 = M.s_c1[swim_slot], s2 = M.s_c2[swim_slot];
+      const float4 s0 = STAB(swim_slot, 0), s1 = STAB(swim_slot, 1), s2 = STAB(swim_slot, 2);
       v3 fo, to;
       if (drag_link(r_com, r_q, r_q, r_lin, r_ang, s0, s1, s2.x, A, &fo, &to)) {
         float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
@@ -544,10 +534,10 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
   const bool isd = lane < nv;
   const int dl = isd ? lane : 0;
   // dof-role constants that index loops stay resident (2 VGPRs); everything else is re-read per step
-  const int4 d_info0 = M.d_info[dl];
+  const int4 d_info0 = DTABI(dl, 0);
   const int ddepth = isd ? d_info0.y : 0;
   const int dsub = isd ? d_info0.z : 0;
-  const int dparent = (CONS && isd) ? M.d_parent[dl] : 0;
+  const int dparent = (CONS && isd) ? DTABI(dl, 2).w : 0;
 
   // ---- load tables + state -------------------------------------------------------------------------
   {
@@ -564,7 +554,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
   }
   float cy_limfrc = 0.f;                            // carried joint-limit force of this dof's joint (physics.py:484-487)
-  if (CONS && FUSED && isd) { const int4 da0 = M.d_act[dl]; if (M.d_prm[dl].w != 0.f) cy_limfrc = A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
+  if (CONS && FUSED && isd) { const int4 da0 = DTABI(dl, 2); if (DTAB(dl, 1).w != 0.f) cy_limfrc = A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
   float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
   float cy_actsum = 0.f;                            // carried motor torque (physics.py:510-524)
   if (FUSED) {
@@ -578,12 +568,12 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       *(float4*)(CY + lane * 16 + 8) = make_float4(ip[1], ip[2], sd[0], sd[1]);
       *(float4*)(CY + lane * 16 + 12) = make_float4(sd[2], sd[3], sd[4], sd[5]);
     }
-    const float4 dp = M.d_prm[dl];
+    const float4 dp = DTAB(dl, 1);
     if (isd && dp.w != 0.f) {
-      const int4 da = M.d_act[dl];
+      const int4 da = DTABI(dl, 2);
       const float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
 #pragma unroll
-      for (int a = 0; a < 4; a++) if (a < da.y) cy_actsum += sa[M.a_src[da.x + a]] * A.inv_torques;
+      for (int a = 0; a < 4; a++) if (a < da.y) cy_actsum += sa[__float_as_int(ATAB(da.x + a, 2).x)] * A.inv_torques;
     }
   }
   if (!(FUSED && A.do_drag) && A.xfrc_applied && isb) {
@@ -610,7 +600,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     const int blo = opaque(bl), dlo = opaque(dl);
     // ============ before_step (reference task.py:168-186) ============
     if (FUSED) {      // links row + drag from the fields the last forward pass left (carried in LDS)
-      const int4 ci2 = M.b_info2[blo];
+      const int4 ci2 = BTABI(blo, 8);
       const int cl = lane < nb ? lane : 0;
       const float4 c0 = *(const float4*)(CY + cl * 16), c1 = *(const float4*)(CY + cl * 16 + 4);
       const float4 c2 = *(const float4*)(CY + cl * 16 + 8), c3 = *(const float4*)(CY + cl * 16 + 12);
@@ -621,8 +611,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     STAMP(0);   // emit links + drag
     // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
     if (FUSED && A.do_readout) {
-      const int4 di = M.d_info[dlo];
-      const float4 dp = M.d_prm[dlo];
+      const int4 di = DTABI(dlo, 0);
+      const float4 dp = DTAB(dlo, 1);
       if (isd && dp.w != 0.f && di.w >= 0) {
         const int index = it % A.buffer_size;
         float* row = A.joints + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
@@ -635,16 +625,16 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
 
     STAMP(1);   // joints row
     // ============ mj_step ============
-    const int4 c_info = M.b_info[blo];        // parent, jtype, qadr, dadr
+    const int4 c_info = BTABI(blo, 7);        // parent, jtype, qadr, dadr
     const int jtype = isb ? c_info.y : -1;
     const int qadr = c_info.z, dadr = c_info.w;
-    const float4 c_axis_q0 = M.j_axis_q0[blo];
-    const float4 c_jpos_k = M.j_pos_k[blo];
+    const float4 c_axis_q0 = BTAB(blo, 5);
+    const float4 c_jpos_k = BTAB(blo, 6);
     // ---- K: local transforms, composed along the chains by pointer jumping (log2(depth) rounds)
     v3 xp; q4 xq;
     {
-      const float4 c_pos_mass = M.b_pos_mass[blo];
-      const float4 c_quat = M.b_quat[blo];
+      const float4 c_pos_mass = BTAB(blo, 0);
+      const float4 c_quat = BTAB(blo, 1);
       xp = mk3(c_pos_mass.x, c_pos_mass.y, c_pos_mass.z);
       xq.w = c_quat.x; xq.x = c_quat.y; xq.y = c_quat.z; xq.z = c_quat.w;
       if (jtype == FMJ_JNT_FREE) {
@@ -685,19 +675,19 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     STAMP(2);   // K
     v3 xi;
     {
-      const float4 c_ipos = M.b_ipos[blo];
+      const float4 c_ipos = BTAB(blo, 2);
       xi = add3(xp, qrot(xq, mk3(c_ipos.x, c_ipos.y, c_ipos.z)));
     }
     // ---- C: tree CoM (wave reduction, result is wave-uniform), cinert, cdof
-    const float mass = isb ? M.b_pos_mass[blo].w : 0.f;
+    const float mass = isb ? BTAB(blo, 0).w : 0.f;
     v3 com;
     com.x = bcast(wave_sum(mass * xi.x), 0) * M.mtot_inv;
     com.y = bcast(wave_sum(mass * xi.y), 0) * M.mtot_inv;
     com.z = bcast(wave_sum(mass * xi.z), 0) * M.mtot_inv;
     float iw[6];     // world-frame inertia about the body's own CoM
     {
-      const float4 c_iquat = M.b_iquat[blo];
-      const float4 c_inertia = M.b_inertia[blo];
+      const float4 c_iquat = BTAB(blo, 3);
+      const float4 c_inertia = BTAB(blo, 4);
       q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
       const m33 Ri = q2m(qmul(xq, iq));
       const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
@@ -821,7 +811,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize): accumulated force
     // (about the tree CoM) and composite inertia about the body's own CoM, shifted to the subtree CoM.
     {
-      const int bsub = isb ? M.b_info2[blo].y : 0;
+      const int bsub = isb ? BTABI(blo, 8).y : 0;
       float cm = 0.f; v3 mr = mk3(0.f, 0.f, 0.f);
       float ic[6];
       s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
@@ -865,12 +855,12 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
     float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
-    const float4 d_prm = M.d_prm[dlo];             // armature, damping, qposadr bits, hinge/slide flag
-    const int4 d_act = M.d_act[dlo];               // first actuator, count, joint sensor slot
+    const float4 d_prm = DTAB(dlo, 1);             // armature, damping, qposadr bits, hinge/slide flag
+    const int4 d_act = DTABI(dlo, 2);               // first actuator, count, joint sensor slot
     const int d_qadr = __float_as_int(d_prm.z);
     const bool d_scalar = isd && d_prm.w != 0.f;
     if (isd) {
-      const int body = M.d_info[dlo].x;
+      const int body = DTABI(dlo, 0).x;
       const s6 cd = lds_get6(CD + lane * 8);
       {
         const float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
@@ -886,7 +876,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       if (d_scalar) {
         const float qj = QP[d_qadr];
         if (M.any_stiffness) {
-          const float kst = M.j_pos_k[body].w;
+          const float kst = BTAB(body, 6).w;
           if (kst != 0.f) qfrc -= kst * (qj - A.qpos_spring[(size_t)env * nq + d_qadr]);
         }
         float asum = 0.f;
@@ -900,8 +890,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
         for (int a = 0; a < 4; a++) {                 // mj_fwdActuation, joint transmission
           if (a < d_act.y) {
-            const int ai = d_act.x + a, src = M.a_src[ai];
-            const float4 p = M.a_prm[ai], lim = M.a_lim[ai];
+            const int ai = d_act.x + a, src = __float_as_int(ATAB(ai, 2).x);
+            const float4 p = ATAB(ai, 0), lim = ATAB(ai, 1);
             float c;
             if (FUSED && A.controller == 1) c = A.w_amp[src] * sinf(cbase - A.w_lag[src]);
             else c = A.ctrl ? A.ctrl[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
@@ -917,10 +907,10 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         cy_actsum = asum * A.inv_torques;
         if (last) {
           float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;   // actuatorfrc
-          if (0 < d_act.y) sa[M.a_src[d_act.x + 0]] = af0;
-          if (1 < d_act.y) sa[M.a_src[d_act.x + 1]] = af1;
-          if (2 < d_act.y) sa[M.a_src[d_act.x + 2]] = af2;
-          if (3 < d_act.y) sa[M.a_src[d_act.x + 3]] = af3;
+          if (0 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 0, 2).x)] = af0;
+          if (1 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 1, 2).x)] = af1;
+          if (2 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 2, 2).x)] = af2;
+          if (3 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 3, 2).x)] = af3;
         }
       }
     }
@@ -933,8 +923,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
       for (int rr = 0; rr < MAXR; rr++) {
         const int e = lane + 64 * rr;
-        tt[rr] = e < M.nMpad ? M.m_tab[e] : 0u;
-        ta[rr] = e < M.nMpad ? M.m_add[e] : 0.f;
+        tt[rr] = e < M.nMpad ? __float_as_uint_(MTAB(e).x) : 0u;
+        ta[rr] = e < M.nMpad ? MTAB(e).y : 0.f;
       }
 #pragma unroll
       for (int rr = 0; rr < MAXR; rr++) {
@@ -947,12 +937,12 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
           const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
           HR[i * RS + dep] = mij + ta[rr];
-          if (CONS) HM[i * RS + dep] = mij + M.m_arm[lane + 64 * rr];
+          if (CONS) HM[i * RS + dep] = mij + MTAB(lane + 64 * rr).z;
         }
       }
 #pragma unroll 1
       for (int e = lane + 64 * MAXR; e < M.nMpad; e += 64) {     // models with more than 512 entries
-        const uint32_t t = M.m_tab[e];
+        const uint32_t t = __float_as_uint_(MTAB(e).x);
         if (t >> 24) {
           const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
           const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
@@ -960,8 +950,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           const float sz = CI[body * 12 + 8];
           const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
           const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
-          HR[i * RS + dep] = mij + M.m_add[e];
-          if (CONS) HM[i * RS + dep] = mij + M.m_arm[e];
+          HR[i * RS + dep] = mij + MTAB(e).y;
+          if (CONS) HM[i * RS + dep] = mij + MTAB(e).z;
         }
       }
     }
@@ -980,7 +970,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; }
       // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
-      const float4 lim = M.d_lim[dlo];
+      const float4 lim = DTAB(dlo, 3);
       float dist_lo = 0.f, dist_hi = 0.f; bool act_lo = false, act_hi = false;
       if (d_scalar && lim.x != 0.f) {
         const float qj = QP[d_qadr];
@@ -995,14 +985,14 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       // (3) plane contacts: lane = geom; contacts ordered by (plane, geom, segment) like the oracle
       int ncon = 0;
       for (int pl = 0; pl < M.nplane; pl++) {
-        const float4 pn = M.p_plane[pl], pp = M.p_prm[pl];
+        const float4 pn = PTAB(pl, 0), pp = PTAB(pl, 1);
         for (int g0 = 0; g0 < M.ngeom; g0 += 64) {
           const int g = g0 + lane;
           bool a0 = false, a1 = false; v3 c0 = mk3(0.f, 0.f, 0.f), c1 = c0; float d0 = 0.f, d1 = 0.f, rad = 0.f, mu = 0.f;
           if (g < M.ngeom) {
-            const int4 gi = M.g_info[g];
+            const int4 gi = GTABI(g, 0);
             if (gi.x == FMJ_GEOM_SPHERE || gi.x == FMJ_GEOM_CAPSULE) {
-              const float4 gs = M.g_size[g], gp = M.g_pos[g], gq = M.g_quat[g];
+              const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
               const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
               const q4 bqq = {bq.x, bq.y, bq.z, bq.w};
               const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
@@ -1054,7 +1044,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           const float* ct = CT + c * 16;
           const float4 c0 = *(const float4*)(ct), c1 = *(const float4*)(ct + 4), c2 = *(const float4*)(ct + 8), c3 = *(const float4*)(ct + 12);
           const int g = __float_as_int(c3.z);
-          const int last = M.g_info[g].z;                       // last dof on the contact body's chain
+          const int last = GTABI(g, 0).z;                       // last dof on the contact body's chain
           const bool on = isd && last >= 0 && lane <= last && last < lane + dsub;
           const v3 jp = add3(cd.l, cross(cd.r, sub3(mk3(c0.x, c0.y, c0.z), com)));
           const float jn = on ? dot3(jp, mk3(c0.w, c1.x, c1.y)) : 0.f;
@@ -1079,12 +1069,12 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         if (is_con) {
           const float4 c3 = *(const float4*)(CT + (tid & 0xffff) * 16 + 12);
           const int g = __float_as_int(c3.z);
-          const float4 a = M.g_sol0[g], b = M.g_sol1[g];
+          const float4 a = GTAB(g, 4), b = GTAB(g, 5);
           sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z;
-          const float tran = M.g_pos[g].w;                       // invweight0 of the body (+ 0 for the world plane)
+          const float tran = GTAB(g, 2).w;                       // invweight0 of the body (+ 0 for the world plane)
           dapx = tran + mu * mu * tran;
         } else {
-          const float4 a = M.d_sol0[tid], b = M.d_sol1[tid];
+          const float4 a = DTAB(tid, 4), b = DTAB(tid, 5);
           sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z; dapx = b.w;
         }
         float R, kimp, bb;
@@ -1275,7 +1265,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
 __global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const StepArgs A) {
   const int env = blockIdx.x;
   for (int s = threadIdx.x; s < M.ns; s += 64) {
-    const float4 s0 = M.s_c0[s], s1 = M.s_c1[s], s2 = M.s_c2[s];
+    const float4 s0 = STAB(s, 0), s1 = STAB(s, 1), s2 = STAB(s, 2);
     const int li = __float_as_int(s2.y), xi = __float_as_int(s2.z), body = __float_as_int(s2.w);
     const float* row = A.links + ((size_t)env * M.n_links + li) * FMJ_LINK_SIZE;
     const float4 a = *(const float4*)(row), b = *(const float4*)(row + 4), c = *(const float4*)(row + 8),
@@ -1326,13 +1316,13 @@ __global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, 
   const float* sa = sd + 6 * (nb - 1) + 3 * M.njs;
   for (int i = threadIdx.x; i < M.n_joints; i += 64) {
     const int d = joints_dof[i];
-    const float4 prm = M.d_prm[d];
-    const int4 act = M.d_act[d];
+    const float4 prm = DTAB(d, 1);
+    const int4 act = DTABI(d, 2);
     float* row = A.joints + ((size_t)env * M.n_joints + i) * FMJ_JOINT_SIZE;
     row[FMJ_JOINT_POSITION] = A.qpos[(size_t)env * M.nq + __float_as_int(prm.z)];
     row[FMJ_JOINT_VELOCITY] = A.qvel[(size_t)env * M.nv + d] * A.inv_angvel;
     float t = 0.f;
-    for (int a = 0; a < act.y; a++) t += sa[M.a_src[act.x + a]] * A.inv_torques;
+    for (int a = 0; a < act.y; a++) t += sa[__float_as_int(ATAB(act.x + a, 2).x)] * A.inv_torques;
     row[FMJ_JOINT_TORQUE] = t;
     row[FMJ_JOINT_LIMIT_FORCE] = sd[6 * (nb - 1) + 3 * act.z + 2] * A.inv_torques;
   }
@@ -1428,6 +1418,15 @@ static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) 
   return FMJ_OK;
 }
 
+// re-pack the host-mutable int fields (link row / swim slot / joint row) and refresh the device tables
+static int sync_tables(fmj_ctx* c) {
+  for (int b = 0; b < 64; b++) c->h_btab[b * BT_STRIDE + 8] = make_float4(ibits(c->h_b_info2[4 * b]), ibits(c->h_b_info2[4 * b + 1]), ibits(c->h_b_info2[4 * b + 2]), ibits(c->h_b_info2[4 * b + 3]));
+  for (int d = 0; d < 64; d++) c->h_dtab[d * DT_STRIDE] = make_float4(ibits(c->h_d_info[4 * d]), ibits(c->h_d_info[4 * d + 1]), ibits(c->h_d_info[4 * d + 2]), ibits(c->h_d_info[4 * d + 3]));
+  HIP_TRY(hipMemcpy(c->d_btab, c->h_btab.data(), c->h_btab.size() * sizeof(float4), hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(c->d_dtab, c->h_dtab.data(), c->h_dtab.size() * sizeof(float4), hipMemcpyHostToDevice));
+  return FMJ_OK;
+}
+
 extern "C" {
 
 const char* fmj_last_error(void) { return g_err.c_str(); }
@@ -1508,7 +1507,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
 
   fmj_ctx* c = new fmj_ctx();
   c->device = device; c->n_envs = n_envs; c->nbody = nb; c->nv = nv; c->nu = nu; c->njnt = nj;
-  c->d_b_info2 = nullptr; c->d_d_info = nullptr;
+  c->d_btab = nullptr; c->d_dtab = nullptr;
   DevModel& D = c->dm;
   memset(&D, 0, sizeof D);
   D.nbody = nb; D.nv = nv; D.nq = nq; D.nu = nu; D.njnt = nj; D.nM = m->nM;
@@ -1605,13 +1604,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->h_b_info2.assign((int*)b_info2.data(), (int*)b_info2.data() + 64 * 4);
   c->h_d_info.assign((int*)d_info.data(), (int*)d_info.data() + 64 * 4);
 
-  UP(b_pos_mass, b_pos_mass); UP(b_quat, b_quat); UP(b_ipos, b_ipos); UP(b_iquat, b_iquat); UP(b_inertia, b_inertia);
-  UP(j_axis_q0, j_axis_q0); UP(j_pos_k, j_pos_k); UP(b_info, b_info); UP(b_info2, b_info2); UP(b_anc, b_anc);
-  UP(d_info, d_info); UP(d_prm, d_prm); UP(d_act, d_act); UP(a_prm, a_prm); UP(a_lim, a_lim); UP(a_src, a_src);
-  UP(m_tab, m_tab); UP(m_add, m_add);
-  c->d_b_info2 = (int4*)D.b_info2; c->d_d_info = (int4*)D.d_info;
-  std::vector<float4> empty4(1, f4(0, 0, 0, 0));
-  UP(empty4, s_c0); UP(empty4, s_c1); UP(empty4, s_c2);
+  UP(b_anc, b_anc);
   // ---- constraint tables
   D.cons = cons; D.ngeom = m->ngeom; D.nplane = nplane; D.nvs = nv | 1;
   D.max_contacts = cons ? (m->max_contacts > 0 ? m->max_contacts : 1) : 0;
@@ -1659,8 +1652,28 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       d_sol1[d] = f4(m->jnt_solimp[5 * j + 2], m->jnt_solimp[5 * j + 3], m->jnt_solimp[5 * j + 4], m->dof_invweight0[d]);
     }
   }
-  UP(m_arm, m_arm); UP(d_parent, d_parent); UP(g_info, g_info); UP(g_size, g_size); UP(g_pos, g_pos); UP(g_quat, g_quat);
-  UP(g_sol0, g_sol0); UP(g_sol1, g_sol1); UP(p_plane, p_plane); UP(p_prm, p_prm); UP(d_lim, d_lim); UP(d_sol0, d_sol0); UP(d_sol1, d_sol1);
+  // ---- pack the tables (one device array per family)
+  auto i4f = [](int4 v) { return make_float4(ibits(v.x), ibits(v.y), ibits(v.z), ibits(v.w)); };
+  c->h_btab.assign(64 * BT_STRIDE, f4(0, 0, 0, 0)); c->h_dtab.assign(64 * DT_STRIDE, f4(0, 0, 0, 0));
+  for (int b = 0; b < 64; b++) {
+    float4* t = &c->h_btab[b * BT_STRIDE];
+    t[0] = b_pos_mass[b]; t[1] = b_quat[b]; t[2] = b_ipos[b]; t[3] = b_iquat[b]; t[4] = b_inertia[b]; t[5] = j_axis_q0[b]; t[6] = j_pos_k[b];
+    t[7] = i4f(b_info[b]); t[8] = i4f(b_info2[b]);
+  }
+  for (int d = 0; d < 64; d++) {
+    float4* t = &c->h_dtab[d * DT_STRIDE];
+    int4 act = d_act[d]; act.w = d_parent[d];
+    t[0] = i4f(d_info[d]); t[1] = d_prm[d]; t[2] = i4f(act); t[3] = d_lim[d]; t[4] = d_sol0[d]; t[5] = d_sol1[d];
+  }
+  std::vector<float4> atab((a_src.size() ? a_src.size() : 1) * AT_STRIDE, f4(0, 0, 0, 0)), mtab(nMpad ? nMpad : 1, f4(0, 0, 0, 0));
+  for (size_t a = 0; a < a_src.size(); a++) { atab[a * AT_STRIDE] = a_prm[a]; atab[a * AT_STRIDE + 1] = a_lim[a]; atab[a * AT_STRIDE + 2] = make_float4(ibits(a_src[a]), 0.f, 0.f, 0.f); }
+  for (int e2 = 0; e2 < nMpad; e2++) mtab[e2] = make_float4(ibits((int)m_tab[e2]), m_add[e2], m_arm[e2], 0.f);
+  std::vector<float4> gtab(g_info.size() * GT_STRIDE), ptab(p_plane.size() * PT_STRIDE);
+  for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
+  for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; }
+  UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(mtab, mtab); UP(gtab, gtab); UP(ptab, ptab);
+  c->d_btab = (float4*)D.btab; c->d_dtab = (float4*)D.dtab;
+  { std::vector<float4> empty4(ST_STRIDE, f4(0, 0, 0, 0)); UP(empty4, stab); }
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
   c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
   for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
@@ -1707,9 +1720,11 @@ int fmj_set_swimming(fmj_ctx* c, int32_t ns, const int32_t* links_index, const i
     c->h_b_info2[4 * b + 3] = s;
     if (xfrc_index[s] + 1 > max_x) max_x = xfrc_index[s] + 1;
   }
+  std::vector<float4> stab((ns ? ns : 1) * ST_STRIDE, f4(0, 0, 0, 0));
+  for (int s2 = 0; s2 < ns; s2++) { stab[s2 * ST_STRIDE] = c0[s2]; stab[s2 * ST_STRIDE + 1] = c1[s2]; stab[s2 * ST_STRIDE + 2] = c2[s2]; }
   int rc;
-  if ((rc = upload(c, c0, &c->dm.s_c0)) || (rc = upload(c, c1, &c->dm.s_c1)) || (rc = upload(c, c2, &c->dm.s_c2))) return rc;
-  HIP_TRY(hipMemcpy(c->d_b_info2, c->h_b_info2.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
+  if ((rc = upload(c, stab, &c->dm.stab))) return rc;
+  if ((rc = sync_tables(c))) return rc;
   c->dm.ns = ns;
   if (max_x > c->dm.n_xfrc) c->dm.n_xfrc = max_x;
   return FMJ_OK;
@@ -1730,8 +1745,7 @@ int fmj_set_readout_maps(fmj_ctx* c, int32_t n_links, const int32_t* links_body,
     if (j < 0 || j >= c->njnt || c->jnt_type[j] == FMJ_JNT_FREE) return set_err(FMJ_ERR_ARG, "fmj_set_readout_maps: joint rows must be hinge/slide joints");
     c->h_d_info[4 * c->jnt_dofadr[j] + 3] = i;
   }
-  HIP_TRY(hipMemcpy(c->d_b_info2, c->h_b_info2.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(c->d_d_info, c->h_d_info.data(), 64 * sizeof(int4), hipMemcpyHostToDevice));
+  { int rc2 = sync_tables(c); if (rc2) return rc2; }
   c->dm.n_links = n_links; c->dm.n_joints = n_joints;
   if (c->dm.n_xfrc < n_links) c->dm.n_xfrc = n_links;
   return FMJ_OK;
