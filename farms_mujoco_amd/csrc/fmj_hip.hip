@@ -212,6 +212,7 @@ __device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wa
 // Hides a value from loop-invariant code motion: per-body model constants are re-read from the
 // (L1/L2-resident) tables inside every step instead of pinning ~40 VGPRs across the whole loop.
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
+__device__ __forceinline__ float pinf(float x) { asm volatile("" : "+v"(x)); return x; }
 // LDS ordering between lanes of the one wave that forms the workgroup
 #define WSYNC() __syncthreads()
 #define WSYNC_LOCAL() __builtin_amdgcn_wave_barrier()
@@ -318,6 +319,35 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   }
   L.total = o;
   return L;
+}
+
+// ---- wave-wide inclusive prefix sum in fp64 with DPP (no LDS): row_shr 1/2/4/8 inside 16-lane rows, then
+// row_bcast:15 / row_bcast:31 across rows (GFX9 DPP controls; same sequence LLVM's atomic optimizer emits).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  return __hiloint2double(hi2, lo2);
+}
+__device__ __forceinline__ double wave_prefix_f64(double v) {
+  v += dpp_f64<0x111, 0xF>(v);
+  v += dpp_f64<0x112, 0xF>(v);
+  v += dpp_f64<0x114, 0xF>(v);
+  v += dpp_f64<0x118, 0xF>(v);
+  v += dpp_f64<0x142, 0xA>(v);
+  v += dpp_f64<0x143, 0xC>(v);
+  return v;
+}
+__device__ __forceinline__ double lane_gather_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2loint(v));
+  const int hi = __builtin_amdgcn_ds_bpermute(src_lane << 2, __double2hiint(v));
+  return __hiloint2double(hi, lo);
+}
+// Sum of x over the contiguous DFS subtree [lane, last] from the inclusive prefix P: P[last] - P[lane] + x
+__device__ __forceinline__ double subtree_sum_f64(double x, int last) {
+  const double P = wave_prefix_f64(x);
+  return lane_gather_f64(P, last) - P + x;
 }
 
 // ---- sparse L'DL on depth-indexed rows (MuJoCo's mj_factorI / mj_solveLD on the dof tree) --------------------
@@ -701,14 +731,6 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
         for (int k = 0; k < 6; k++) iw[k] = 0.f;
       }
-      if (lane < nb) {
-        // LDS gets the LOCAL description (inertia about the body's own CoM, CoM, mass): S assembles each
-        // composite inertia about its own subtree CoM, avoiding the m*d^2 inflation (and the fp32
-        // cancellation it causes in M) of inertias taken about the distant tree CoM.
-        *(float4*)(CI + lane * 12) = make_float4(iw[0], iw[1], iw[2], iw[3]);
-        *(float4*)(CI + lane * 12 + 4) = make_float4(iw[4], iw[5], xi.x, xi.y);
-        *(float2*)(CI + lane * 12 + 8) = make_float2(xi.z, mass);
-      }
     }
     STAMP(3);   // C
     // ---- V: joint velocity vJ, then cvel = chain sum of vJ, cacc = a0 + chain sum of cvel_parent x vJ
@@ -767,6 +789,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     }
     STAMP(4);   // V
     // ---- F: body force (inertial minus external), about the common point
+    s6 fbody;
     {
       // cinert * v with cinert = {Iw, d = xi - com, m} (MuJoCo's cinert about the tree CoM, never materialised):
       // lin = p = m (u + w x d),  rot = Iw w + d x p
@@ -783,7 +806,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       f.r = sub3(f.r, add3(tw, cross(sub3(xi, com), fw)));
       f.l = sub3(f.l, fw);
       if (!isb) { f.r = f.l = mk3(0.f, 0.f, 0.f); }
-      if (lane < nb) lds_put6(F + lane * 8, f);
+      fbody = f;
     }
     // ---- sensors of this (pre-integration) state; they are next iteration's link data (mj_step lag)
     {
@@ -808,43 +831,41 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     }
     WSYNC();
     STAMP(5);   // F + carry
-    // ---- S: subtree sums over the contiguous DFS range [lane, lane + subsize): accumulated force
-    // (about the tree CoM) and composite inertia about the body's own CoM, shifted to the subtree CoM.
+    // ---- S: subtree sums over the contiguous DFS id range [lane, lane + subsize) as prefix-sum differences
+    // (Euler-tour trick).  The sums are taken about the tree CoM in fp64 - a subtree total is the difference
+    // of two prefixes that can be 1e4 times larger, which fp32 cannot carry - and the composite inertia is
+    // then moved to the subtree's own CoM s (parallel-axis shift, still fp64), so everything M sees is local.
     {
-      const int bsub = isb ? BTABI(blo, 8).y : 0;
-      float cm = 0.f; v3 mr = mk3(0.f, 0.f, 0.f);
-      float ic[6];
-      s6 fs = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
-#pragma unroll
-      for (int k = 0; k < 6; k++) ic[k] = 0.f;
-#pragma unroll 1
-      for (int k = 0; k < M.max_subsize; k++) {
-        if (k < bsub) {
-          const int d = lane + k;
-          const float4 a = *(const float4*)(CI + d * 12), b = *(const float4*)(CI + d * 12 + 4);
-          const float2 c = *(const float2*)(CI + d * 12 + 8);
-          const float md = c.y;
-          const v3 rr = sub3(mk3(b.z, b.w, c.x), xi);
-          cm += md; mr = add3(mr, scl3(rr, md));
-          ic[0] += a.x + md * (rr.y * rr.y + rr.z * rr.z);
-          ic[1] += a.y + md * (rr.x * rr.x + rr.z * rr.z);
-          ic[2] += a.z + md * (rr.x * rr.x + rr.y * rr.y);
-          ic[3] += a.w - md * rr.x * rr.y;
-          ic[4] += b.x - md * rr.x * rr.z;
-          ic[5] += b.y - md * rr.y * rr.z;
-          fs = s6add(fs, lds_get6(F + d * 8));
-        }
-      }
-      const float cminv = cm > 0.f ? 1.0f / cm : 0.f;
-      const v3 dlt = scl3(mr, cminv);                // subtree CoM relative to this body's CoM
-      const v3 sc = add3(xi, dlt);
-      ic[0] -= cm * (dlt.y * dlt.y + dlt.z * dlt.z); ic[1] -= cm * (dlt.x * dlt.x + dlt.z * dlt.z); ic[2] -= cm * (dlt.x * dlt.x + dlt.y * dlt.y);
-      ic[3] += cm * dlt.x * dlt.y; ic[4] += cm * dlt.x * dlt.z; ic[5] += cm * dlt.y * dlt.z;
-      WSYNC();
+      const int last = isb ? lane + BTABI(blo, 8).y - 1 : lane;
+      const double dm = (double)mass;
+      const double dx = (double)xi.x - (double)com.x, dy = (double)xi.y - (double)com.y, dz = (double)xi.z - (double)com.z;
+      const double ms = subtree_sum_f64(dm, last);
+      const double px = subtree_sum_f64(dm * dx, last), py = subtree_sum_f64(dm * dy, last), pz = subtree_sum_f64(dm * dz, last);
+      const double minv = ms > 0.0 ? 1.0 / ms : 0.0;
+      const double ex = px * minv, ey = py * minv, ez = pz * minv;           // subtree CoM relative to the tree CoM
+      // one scan at a time: pinf() (asm volatile) fences keep the compiler from forming all sixteen fp64 inputs
+      // up front, which would cost ~50 VGPRs; each result is converted to fp32 at once
+#define SCAN(expr) pinf((float)(expr))
+      const float m0 = pinf(mass), d0 = pinf((float)dx), d1 = pinf((float)dy), d2 = pinf((float)dz);
+      (void)m0; (void)d0; (void)d1; (void)d2;
+      const float i0 = SCAN(subtree_sum_f64((double)pinf(iw[0]) + dm * (dy * dy + dz * dz), last) - ms * (ey * ey + ez * ez));
+      const float i1 = SCAN(subtree_sum_f64((double)pinf(iw[1]) + dm * (dx * dx + dz * dz), last) - ms * (ex * ex + ez * ez));
+      const float i2 = SCAN(subtree_sum_f64((double)pinf(iw[2]) + dm * (dx * dx + dy * dy), last) - ms * (ex * ex + ey * ey));
+      const float i3 = SCAN(subtree_sum_f64((double)pinf(iw[3]) - dm * dx * dy, last) + ms * ex * ey);
+      const float i4 = SCAN(subtree_sum_f64((double)pinf(iw[4]) - dm * dx * dz, last) + ms * ex * ez);
+      const float i5 = SCAN(subtree_sum_f64((double)pinf(iw[5]) - dm * dy * dz, last) + ms * ey * ez);
+      s6 fs;
+      fs.r.x = SCAN(subtree_sum_f64((double)pinf(fbody.r.x), last));
+      fs.r.y = SCAN(subtree_sum_f64((double)pinf(fbody.r.y), last));
+      fs.r.z = SCAN(subtree_sum_f64((double)pinf(fbody.r.z), last));
+      fs.l.x = SCAN(subtree_sum_f64((double)pinf(fbody.l.x), last));
+      fs.l.y = SCAN(subtree_sum_f64((double)pinf(fbody.l.y), last));
+      fs.l.z = SCAN(subtree_sum_f64((double)pinf(fbody.l.z), last));
+#undef SCAN
       if (lane < nb) {
-        *(float4*)(CI + lane * 12) = make_float4(ic[0], ic[1], ic[2], ic[3]);
-        *(float4*)(CI + lane * 12 + 4) = make_float4(ic[4], ic[5], sc.x, sc.y);
-        *(float2*)(CI + lane * 12 + 8) = make_float2(sc.z, cm);
+        *(float4*)(CI + lane * 12) = make_float4(i0, i1, i2, i3);
+        *(float4*)(CI + lane * 12 + 4) = make_float4(i4, i5, (float)((double)com.x + ex), (float)((double)com.y + ey));
+        *(float2*)(CI + lane * 12 + 8) = make_float2((float)((double)com.z + ez), (float)ms);
         lds_put6(F + lane * 8, fs);
       }
     }
