@@ -99,7 +99,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=1000)
-    ap.add_argument('--warmup', type=int, default=500)
+    ap.add_argument('--warmup', type=int, default=3000)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--chunk', type=int, default=100, help='steps per fused launch (= ring-buffer length)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

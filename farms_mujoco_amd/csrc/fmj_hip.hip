@@ -356,14 +356,16 @@ __device__ __forceinline__ double subtree_sum_f64(double x, int last) {
 // tracked in its own register so D_k comes from a v_readlane before the LDS round trip.  Slots past a lane's
 // depth only ever hold finite garbage that is never read as a matrix entry (the caller zero-fills HR before
 // assembling the matrix).  On return HR holds the final rows (L*D) and dinv = 1/D_lane.
+typedef float f2_t __attribute__((ext_vector_type(2)));
 template <int MAXD>
-__device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int ddepth, int dsub, int nv, float (&r)[MAXD], float& dinv_mine) {
+__device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int ddepth, int dsub, int nv, float& dinv_mine) {
   constexpr int RS = MAXD;
+  f2_t r[MAXD / 2];                                // row in registers as float pairs: the update is v_pk_fma_f32
 #pragma unroll
   for (int d = 0; d < MAXD; d += 4) {
     float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
     if (isd) t = *(const float4*)(HR + lane * RS + d);
-    r[d] = t.x; r[d + 1] = t.y; r[d + 2] = t.z; r[d + 3] = t.w;
+    r[d / 2] = f2_t{t.x, t.y}; r[d / 2 + 1] = f2_t{t.z, t.w};
   }
   float diag = isd ? HR[lane * RS + ddepth] : 1.f;
   dinv_mine = 0.f;
@@ -375,7 +377,7 @@ __device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int dd
     if (lane == k) {
       dinv_mine = dk_inv;
 #pragma unroll
-      for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
+      for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y);
     }
     WSYNC();
     const float tk = HR[k * RS + ddepth];
@@ -384,11 +386,12 @@ __device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int dd
     for (int g = 0; g < MAXD / 4; g++) rk[g] = *(const float4*)(HR + k * RS + 4 * g);
     const bool anc = lane < k && k < lane + dsub;
     const float t = anc ? tk * dk_inv : 0.f;
+    const f2_t nt = f2_t{-t, -t};
     // all groups, unconditionally: straight-line code beats skipping the (on average 40 %) padding groups
 #pragma unroll
     for (int g = 0; g < MAXD / 4; g++) {
-      r[4 * g] = fmaf(-t, rk[g].x, r[4 * g]); r[4 * g + 1] = fmaf(-t, rk[g].y, r[4 * g + 1]);
-      r[4 * g + 2] = fmaf(-t, rk[g].z, r[4 * g + 2]); r[4 * g + 3] = fmaf(-t, rk[g].w, r[4 * g + 3]);
+      r[2 * g] = __builtin_elementwise_fma(nt, f2_t{rk[g].x, rk[g].y}, r[2 * g]);
+      r[2 * g + 1] = __builtin_elementwise_fma(nt, f2_t{rk[g].z, rk[g].w}, r[2 * g + 1]);
     }
     diag = fmaf(-t, tk, diag);
     WSYNC();
@@ -914,7 +917,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
             const int ai = d_act.x + a, src = __float_as_int(ATAB(ai, 2).x);
             const float4 p = ATAB(ai, 0), lim = ATAB(ai, 1);
             float c;
-            if (FUSED && A.controller == 1) c = A.w_amp[src] * sinf(cbase - A.w_lag[src]);
+            if (FUSED && A.controller == 1) { const float amp = A.w_amp[src]; c = amp != 0.f ? amp * sinf(cbase - A.w_lag[src]) : 0.f; }
             else c = A.ctrl ? A.ctrl[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
             c = fminf(fmaxf(c, lim.x), lim.y);
             float f = p.x * c + p.y + p.z * qj + p.w * qd;
@@ -985,8 +988,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       // (1) factor M, qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
       {
-        float rm[MAXD];
-        ldl_factor<MAXD>(HM, lane, isd, ddepth, dsub, nv, rm, dinv_m);
+        ldl_factor<MAXD>(HM, lane, isd, ddepth, dsub, nv, dinv_m);
       }
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; }
@@ -1217,9 +1219,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     // ---- L + X: sparse L'DL of H = M + diag(armature + h*damping) and the solve H qacc = qfrc_smooth
     float my_qacc;
     {
-      float r[MAXD];
       float dinv_mine;
-      ldl_factor<MAXD>(HR, lane, isd, ddepth, dsub, nv, r, dinv_mine);
+      ldl_factor<MAXD>(HR, lane, isd, ddepth, dsub, nv, dinv_mine);
       STAMP(9);   // L
       my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine);
     }
