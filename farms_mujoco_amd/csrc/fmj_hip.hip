@@ -275,6 +275,39 @@ __device__ __forceinline__ bool drag_link(v3 com_pos, fq urdf2global, fq com2glo
   return true;
 }
 
+// Same law for the fused loop, where the link's CoM orientation IS its body orientation (reference
+// physics.py:455-466 fills both from xquat), so com2urdf is the identity (drag.pyx:46-47,261-262 become no-ops)
+// and every quaternion sandwich q v q* collapses to one rotation matrix: ~80 VALU instead of ~400.
+__device__ __forceinline__ bool drag_link_same_frames(v3 com_pos, q4 q_wxyz, v3 lin_w, v3 ang_w, float4 c0, float4 c1,
+                                                      float density, const StepArgs& A, v3* force_link, v3* force_w, v3* torque_link, v3* torque_w) {
+  if (com_pos.z > A.surface) return false;                     // drag.pyx:192-194
+  const m33 R = q2m(q_wxyz);                                   // link -> world
+  // world -> link = R^T  (drag.pyx:50-63, 235-244)
+  v3 lin = mk3(R.a[0] * lin_w.x + R.a[3] * lin_w.y + R.a[6] * lin_w.z, R.a[1] * lin_w.x + R.a[4] * lin_w.y + R.a[7] * lin_w.z,
+               R.a[2] * lin_w.x + R.a[5] * lin_w.y + R.a[8] * lin_w.z);
+  const v3 ang = mk3(R.a[0] * ang_w.x + R.a[3] * ang_w.y + R.a[6] * ang_w.z, R.a[1] * ang_w.x + R.a[4] * ang_w.y + R.a[7] * ang_w.z,
+                     R.a[2] * ang_w.x + R.a[5] * ang_w.y + R.a[8] * ang_w.z);
+  v3 buoy = mk3(0.f, 0.f, 0.f);
+  const float mass = c0.w, height = c1.w;
+  if (A.use_buoyancy && mass > 0.f && com_pos.z < A.surface) {  // drag.pyx:139-146
+    const float fz = -1000.f * mass * A.wgravity / density * fminf(fmaxf(A.surface - com_pos.z, 0.f) / height, 1.f);
+    buoy = mk3(R.a[6] * fz, R.a[7] * fz, R.a[8] * fz);
+  }
+  if (A.wvx != 0.f || A.wvy != 0.f || A.wvz != 0.f) {
+    lin.x -= R.a[0] * A.wvx + R.a[3] * A.wvy + R.a[6] * A.wvz;
+    lin.y -= R.a[1] * A.wvx + R.a[4] * A.wvy + R.a[7] * A.wvz;
+    lin.z -= R.a[2] * A.wvx + R.a[5] * A.wvy + R.a[8] * A.wvz;
+  }
+  v3 f, t;
+  f.x = fabsf(lin.x) * lin.x * (A.viscosity * c0.x) + buoy.x;   // sign(v) v^2 c visc + buoyancy (drag.pyx:83-88)
+  f.y = fabsf(lin.y) * lin.y * (A.viscosity * c0.y) + buoy.y;
+  f.z = fabsf(lin.z) * lin.z * (A.viscosity * c0.z) + buoy.z;
+  t.x = fabsf(ang.x) * ang.x * c1.x; t.y = fabsf(ang.y) * ang.y * c1.y; t.z = fabsf(ang.z) * ang.z * c1.z;   // :104-108
+  *force_link = f; *torque_link = t;
+  *force_w = mrot(R, f); *torque_w = mrot(R, t);
+  return true;
+}
+
 // ---------------------------------------------------------------------------------------------
 // the step kernel
 
@@ -514,13 +547,12 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
     for (int k = 0; k < 6; k++) xf[k] = 0.f;
     if (isb && swim_slot >= 0) {
       const float4 s0 = STAB(swim_slot, 0), s1 = STAB(swim_slot, 1), s2 = STAB(swim_slot, 2);
-      v3 fo, to;
-      if (drag_link(r_com, r_q, r_q, r_lin, r_ang, s0, s1, s2.x, A, &fo, &to)) {
+      v3 fo, to, fw, tw;
+      if (drag_link_same_frames(r_com, xquat, r_lin, r_ang, s0, s1, s2.x, A, &fo, &fw, &to, &tw)) {
         float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
         *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
         *(float2*)(xr + 2) = make_float2(fo.z, to.x);
         *(float2*)(xr + 4) = make_float2(to.y, to.z);
-        const v3 fw = fq_rot(fo, r_q), tw = fq_rot(to, r_q);
         xf[0] = fw.x * A.newtons; xf[1] = fw.y * A.newtons; xf[2] = fw.z * A.newtons;
         xf[3] = tw.x * A.torques; xf[4] = tw.y * A.torques; xf[5] = tw.z * A.torques;
       }
