@@ -429,9 +429,17 @@ __device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int dd
     diag = fmaf(-t, tk, diag);
     WSYNC();
   }
+  // every lane's register row is final since its own pivot turn: publish it once more, scaled by 1/D, so that
+  // HR holds the unit-triangular factor L itself (diagonal slot = 1) and the solves need no per-entry scaling
+  if (isd) {
+#pragma unroll
+    for (int d = 0; d < MAXD; d += 4)
+      *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x * dinv_mine, r[d / 2].y * dinv_mine, r[d / 2 + 1].x * dinv_mine, r[d / 2 + 1].y * dinv_mine);
+  }
+  WSYNC();
 }
 
-// x = (L' D L)^-1 rhs with v_readlane broadcasts; HR rows hold L*D, so 1/D is folded in.
+// x = (L' D L)^-1 rhs with v_readlane broadcasts; HR rows hold L (see ldl_factor), dinv = 1/D_lane.
 template <int MAXD>
 __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane, bool isd, int ddepth, int dsub, int nv, float dinv_mine) {
   constexpr int RS = MAXD;
@@ -446,13 +454,13 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
 #pragma unroll
       for (int u = 0; u < 8; u++) {
         const bool anc = lane < i - u && i - u < lane + dsub;
-        x = fmaf(anc ? -l[u] : 0.f, bcast(x, i - u) * bcast(dinv_mine, i - u), x);
+        x = fmaf(anc ? -l[u] : 0.f, bcast(x, i - u), x);
       }
     }
 #pragma unroll 1
     for (; i >= 1; i--) {
       const float l = (lane < i && i < lane + dsub) ? HR[i * RS + ddepth] : 0.f;
-      x = fmaf(-l, bcast(x, i) * bcast(dinv_mine, i), x);
+      x = fmaf(-l, bcast(x, i), x);
     }
   }
   x *= dinv_mine;
@@ -466,13 +474,13 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
       for (int u = 0; u < 8; u++) {
         const int subj = __builtin_amdgcn_readlane(dsub, j + u);
         const bool desc = isd && j + u < lane && lane < j + u + subj;
-        x = fmaf(desc ? -l[u] * dinv_mine : 0.f, bcast(x, j + u), x);
+        x = fmaf(desc ? -l[u] : 0.f, bcast(x, j + u), x);
       }
     }
 #pragma unroll 1
     for (; j < nv - 1; j++) {
       const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
-      const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] * dinv_mine : 0.f;
+      const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] : 0.f;
       x = fmaf(-l, bcast(x, j), x);
     }
   }
@@ -1155,7 +1163,6 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f; }
       // (6) Y = J L^-1 (lane = row): y_a -= L[i][a] y_i for every dof i (leaves first) and ancestor a
       for (int i = nv - 1; i >= 1; i--) {
-        const float di = DI[i];
         const int depi = __builtin_amdgcn_readlane(ddepth, i);
         for (int e = lane; e < nefc; e += 64) {
           float* y = YJ + e * nvs;
@@ -1163,7 +1170,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           int a = i;
           for (int dd = depi - 1; dd >= 0; dd--) {
             a = __builtin_amdgcn_readlane(dparent, a);          // uniform parent walk: ancestor at depth dd
-            y[a] = fmaf(-HM[i * RS + dd] * di, yi, y[a]);
+            y[a] = fmaf(-HM[i * RS + dd], yi, y[a]);
           }
         }
       }
@@ -1213,7 +1220,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         const float u = isd ? w / dinv_m : 0.f;                      // (Y' f)_d
         float q = u;
         for (int i = nv - 1; i >= 1; i--) {
-          const float ui = bcast(u, i) * bcast(dinv_m, i);
+          const float ui = bcast(u, i);
           const bool anc = lane < i && i < lane + dsub;
           q = fmaf(anc ? HM[i * RS + ddepth] : 0.f, ui, q);
         }
@@ -1223,7 +1230,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         for (int j = 0; j < nv - 1; j++) {
           const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
           const bool desc = isd && j < lane && lane < j + subj;
-          xa = fmaf(desc ? -HM[dli * RS + depj] * dinv_m : 0.f, bcast(xa, j), xa);
+          xa = fmaf(desc ? -HM[dli * RS + depj] : 0.f, bcast(xa, j), xa);
         }
         if (isd) { const float qa = xs + xa; QW[lane] = qa; if (!(fabsf(qa) <= 1e10f)) warn |= FMJ_WARN_BADQACC; }
       }
