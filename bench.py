@@ -160,6 +160,15 @@ def main():
         alg_bytes_per_launch = b_step*n_envs*chunk
         achieved = alg_bytes_per_launch/avg_launch_s/1e9
         info = sim.physics.kernel_info()
+        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
+        # summary of the same workload, profiles/latest_traffic.json, produced as DESIGN.md section 5 describes.
+        traffic = None
+        try:
+            tr = json.load(open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')))
+            if tr['steps_per_launch'] == chunk and tr['envs'] == n_envs:
+                traffic = tr['fetch_bytes'] + tr['write_bytes']
+        except Exception:
+            pass
         out = {
             'metric': 'env-steps/sec, salamander swim x4096 envs per MI355X',
             'value': n_envs*world*K/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -171,10 +180,12 @@ def main():
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',
                        'lds_bytes_per_env': info['lds_bytes_per_env']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved/HBM_PEAK_GBS, 'traffic': None,
+                         'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
+                         'traffic_note': 'bytes per launch, FETCH_SIZE + WRITE_SIZE as counted (profiles/), algorithmic = '
+                                         f'{alg_bytes_per_launch}',
                          'kernel': 'fmj_step_kernel<true>', 'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b_step,
-                         'note': 'latency/issue-bound tree recursions: HBM is nominal bound (SURVEY 8d)'},
+                         'note': 'VALU-issue-bound tree recursions (profiles/r01_v5_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
