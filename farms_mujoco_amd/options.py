@@ -59,11 +59,30 @@ class AnimatOptions:
     """The slice of farms_core AnimatOptions the hot path reads: ``morphology.links[*].{name, swimming,
     density, drag_coefficients}`` (reference drag.pyx:353-385) and ``control.motors`` (task.py:274-286)."""
 
-    def __init__(self, name='animat', links=(), motors=()):
+    def __init__(self, name='animat', links=(), motors=(), joints=(), sdf=None, spawn_pose=(0, 0, 0, 0, 0, 0),
+                 spawn_velocity=(0, 0, 0, 0, 0, 0), mujoco=None):
         self.name = name
-        self.morphology = SimpleNamespace(links=list(links), joints=[], self_collisions=[])
-        self.control = SimpleNamespace(motors=list(motors))
-        self.mujoco = {}
+        self.sdf = sdf
+        self.spawn = SimpleNamespace(pose=list(spawn_pose), velocity=list(spawn_velocity))
+        self.morphology = SimpleNamespace(links=list(links), joints=list(joints), self_collisions=[])
+        motors = list(motors)
+        self.control = SimpleNamespace(motors=motors, joints_names=lambda: [m_.joint_name for m_ in motors])
+        self.mujoco = dict(mujoco or {})
+
+    @staticmethod
+    def link(name, swimming=False, density=1000.0, drag_coefficients=((0, 0, 0), (0, 0, 0)), friction=(0, 0, 0), height=None):
+        return SimpleNamespace(name=name, swimming=swimming, density=density, drag_coefficients=drag_coefficients,
+                               friction=list(friction), height=height)
+
+    @staticmethod
+    def joint(name, initial=(0.0, 0.0), stiffness=0.0, damping=0.0, extras=None):
+        return SimpleNamespace(name=name, initial=list(initial), stiffness=stiffness, damping=damping, extras=extras or {})
+
+    @staticmethod
+    def motor(joint_name, control_types=('position',), gains=(0.0, 0.0), limits_torque=None, passive=None):
+        return SimpleNamespace(joint_name=joint_name, control_types=list(control_types), gains=list(gains),
+                               limits_torque=limits_torque,
+                               passive=passive or SimpleNamespace(is_passive=False, stiffness_coefficient=0.0, damping_coefficient=0.0))
 
     @classmethod
     def from_model(cls, model):

@@ -1,0 +1,184 @@
+"""Model compiler: SDF + options -> batched model arrays.
+
+Counterpart of reference farms_mujoco/simulation/mjcf.py (``sdf2mjcf`` :647-1035, ``mjc_add_link`` :132-600,
+``setup_mjcf_xml`` :1174-1512) without dm_control / MuJoCo's XML compiler: the SDF tree is walked exactly like
+``add_link_recursive`` (:603-644) and every quantity gets the same unit scaling, but the result is a
+:class:`~farms_mujoco_amd.model.Model` (flat arrays) instead of an MJCF element tree.  Rendering-only content
+(visuals, meshes, textures, cameras, lights) and muscles are out of scope."""
+from __future__ import annotations
+
+import numpy as np
+
+from ..io.sdf import ModelSDF, Link
+from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, DEFAULT_SOLREF,
+                     DEFAULT_SOLIMP)
+from ..units import SimulationUnitScaling
+
+MIN_MASS = 0
+MIN_INERTIA = 0
+
+
+def euler2mjcquat(euler):
+    """Euler (scipy 'xyz': extrinsic x, y, z) to MuJoCo w,x,y,z quaternion (reference mjcf.py:47-53)."""
+    return euler2quat(euler)
+
+
+def euler2mat(euler):
+    return quat2mat(euler2quat(euler))
+
+
+def poseul2mat4d(position, euler):
+    t = np.eye(4)
+    t[:3, -1] = position
+    t[:3, :3] = euler2mat(euler)
+    return t
+
+
+def get_local_transform(parent_pose, child_pose):
+    """Link local transform as (position, rotation matrix) (reference mjcf.py:76-96; the reference converts the
+    rotation back to Euler angles, which it then turns into a quaternion again)."""
+    parent = np.eye(4) if parent_pose is None else poseul2mat4d(parent_pose[:3], parent_pose[3:])
+    local = np.linalg.inv(parent) @ poseul2mat4d(child_pose[:3], child_pose[3:])
+    return local[:3, -1], local[:3, :3]
+
+
+def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
+    """Compile one animat (reference sdf2mjcf, mjcf.py:647-1035 + the animat part of setup_mjcf_xml :1406-1481)."""
+    from ..model import mat2quat
+    fixed_base = kwargs.pop('fixed_base', False)
+    animat_options = kwargs.pop('animat_options', None)
+    simulation_options = kwargs.pop('simulation_options', None)
+    units = kwargs.pop('units', simulation_options.units if simulation_options is not None else SimulationUnitScaling())
+    use_actuators = kwargs.pop('use_actuators', True)
+    use_collisions = kwargs.pop('use_collisions', False)
+    plane = kwargs.pop('plane', False)
+    friction = kwargs.pop('friction', [0, 0, 0])
+    solref = kwargs.pop('solref', None)
+    solimp = kwargs.pop('solimp', None)
+    assert not kwargs, kwargs
+
+    timestep = 1e-3
+    gravity = [0.0, 0.0, -9.81]
+    if simulation_options is not None:                      # reference mjcf.py:1187-1192,1329,1336-1341
+        timestep = simulation_options.timestep/max(int(simulation_options.num_sub_steps), 1)
+        gravity = [g*units.acceleration for g in simulation_options.gravity]
+    b = ModelBuilder(sdf.name, timestep=timestep, gravity=gravity)
+    if simulation_options is not None:
+        b.options['solver_iterations'] = int(simulation_options.n_solver_iters)
+        b.options['impratio'] = float(simulation_options.impratio)
+
+    link_opts = {l.name: l for l in animat_options.morphology.links} if animat_options is not None else {}
+    joint_opts = {j.name: j for j in animat_options.morphology.joints} if animat_options is not None else {}
+    motors = {m_.joint_name: m_ for m_ in animat_options.control.motors} if animat_options is not None else {}
+
+    # wrapper body of the model with the free joint (reference mjcf.py:176-179,716-726); spawn pose: :1409-1413
+    spawn = animat_options.spawn.pose if animat_options is not None and getattr(animat_options, 'spawn', None) else sdf.pose
+    root_name = sdf.name
+    b.add_body(root_name, 'world', pos=[p*units.meters for p in spawn[:3]], quat=euler2mjcquat(spawn[3:]),
+               joint=None if fixed_base else 'free')
+
+    def add_link(link: Link, parent_link, parent_name, joint):
+        pos, rot = get_local_transform(None if parent_link is None else parent_link.pose, link.pose)
+        kw = dict(pos=[p*units.meters for p in pos], quat=mat2quat(rot))
+        if link.inertial is not None:                       # reference mjcf.py:536-589
+            I = link.inertial.inertias
+            mat = np.array([[max(MIN_INERTIA, I[0]), I[1], I[2]], [I[1], max(MIN_INERTIA, I[3]), I[4]],
+                            [I[2], I[4], max(MIN_INERTIA, I[5])]])
+            assert (np.linalg.eigvalsh(mat) > 0).all(), f'Eigen values <= 0 for link {link.name}'
+            R = euler2mat(link.inertial.pose[3:])
+            mat = R @ mat @ R.T
+            kw.update(mass=link.inertial.mass*units.kilograms, ipos=[p*units.meters for p in link.inertial.pose[:3]],
+                      fullinertia=[mat[0, 0]*units.inertia, mat[1, 1]*units.inertia, mat[2, 2]*units.inertia,
+                                   mat[0, 1]*units.inertia, mat[0, 2]*units.inertia, mat[1, 2]*units.inertia])
+        jkw = {}
+        if joint is not None and joint.type in ('revolute', 'continuous', 'prismatic'):    # :181-212
+            jo = joint_opts.get(joint.name)
+            jkw = dict(joint='slide' if joint.type == 'prismatic' else 'hinge', jname=joint.name, axis=joint.axis.xyz,
+                       jpos=[p*units.meters for p in joint.pose[:3]], limited=joint.axis.limits is not None,
+                       range=joint.axis.limits[:2] if joint.axis.limits is not None else (0.0, 0.0))
+            stiffness = damping = 0.0
+            if jo is not None:                              # :1426-1444
+                stiffness += jo.stiffness*units.angular_stiffness
+                damping += jo.damping*units.angular_damping
+                extras = getattr(jo, 'extras', {}) or {}
+                if extras.get('solreflimit'):
+                    sr = list(extras['solreflimit'])
+                    if all(s_ < 0 for s_ in sr):
+                        sr[0] *= units.newtons/units.meters; sr[1] *= units.newtons/units.velocity
+                    else:
+                        sr[0] *= units.seconds
+                    jkw['solreflimit'] = sr
+                if extras.get('solimplimit'):
+                    jkw['solimplimit'] = extras['solimplimit']
+                if extras.get('margin'):
+                    jkw['margin'] = extras['margin']
+                jkw['qpos0'] = 0.0
+            mo = motors.get(joint.name)
+            if mo is not None and getattr(mo, 'passive', None) is not None and mo.passive.is_passive:     # :1456-1462
+                stiffness += mo.passive.stiffness_coefficient*units.angular_stiffness
+                damping += mo.passive.damping_coefficient*units.angular_damping
+            jkw.update(stiffness=stiffness, damping=damping)
+        b.add_body(link.name, parent_name, **kw, **jkw)
+        lo = link_opts.get(link.name)
+        rbound = link.collisions[0].geometry.bounding_radius() if link.collisions else 0.0
+        if lo is not None and getattr(lo, 'swimming', False):
+            height = getattr(lo, 'height', None)
+            b.set_swimming(link.name, density=lo.density, drag_coefficients=lo.drag_coefficients,
+                           height=height if height is not None else 0.5*rbound)          # drag.pyx:364-372
+        if use_collisions:
+            fr = list(lo.friction) if lo is not None and getattr(lo, 'friction', None) is not None else list(friction)
+            for col in link.collisions:                     # :245-267 (margin 0, condim 3)
+                g = col.geometry
+                gkw = dict(pos=[p*units.meters for p in col.pose[:3]], quat=euler2mjcquat(col.pose[3:]), friction=fr,
+                           solref=solref if solref is not None else DEFAULT_SOLREF,
+                           solimp=solimp if solimp is not None else DEFAULT_SOLIMP)
+                if g.kind == 'sphere':
+                    b.add_geom(link.name, GEOM_SPHERE, (g.size[0]*units.meters,), **gkw)
+                elif g.kind == 'capsule':
+                    b.add_geom(link.name, GEOM_CAPSULE, (g.size[0]*units.meters, 0.5*g.size[1]*units.meters), **gkw)
+                else:
+                    raise NotImplementedError(f'collision shape {g.kind!r} of link {link.name} is outside the HIP subset '
+                                              '(sphere / capsule against planes)')
+        for child in sdf.get_children(link):
+            add_link(child, link, link.name, sdf.get_parent_joint(child))
+
+    for root in sdf.get_base_links():
+        add_link(root, None, root_name, None)
+    if plane:
+        b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))            # arena friction 0 (mjcf.py:1202)
+        b.options['max_contacts'] = int(plane) if not isinstance(plane, bool) else 32
+
+    # actuators: position / velocity / motor per joint (:791-866)
+    if use_actuators:
+        joint_names = (animat_options.control.joints_names() if animat_options is not None
+                       else [j.name for j in sdf.joints if j.type in ('revolute', 'continuous', 'prismatic')])
+        for jn in joint_names:
+            mo = motors.get(jn)
+            gains = getattr(mo, 'gains', None) if mo is not None else None
+            lim = getattr(mo, 'limits_torque', None) if mo is not None else None
+            b.add_joint_actuators(jn, kp=gains[0]*units.torques if gains else 0.0,
+                                  kv=gains[1]*units.angular_damping if gains else 0.0,
+                                  forcerange=[t*units.torques for t in lim] if lim is not None else None)
+    m = b.compile()
+    # keyframe "initial" (:744-788): joint initial positions / velocities, spawn velocity
+    for jo in joint_opts.values():
+        if jo.name in m.joint_names:
+            j = m.joint_id(jo.name)
+            m.key_qpos[m.jnt_qposadr[j]] = jo.initial[0]
+            m.key_qvel[m.jnt_dofadr[j]] = jo.initial[1]
+    if not fixed_base and animat_options is not None and getattr(animat_options.spawn, 'velocity', None) is not None:
+        v = animat_options.spawn.velocity
+        m.key_qvel[:3] = [x*units.velocity for x in v[:3]]
+        m.key_qvel[3:6] = [x*units.angular_velocity for x in v[3:6]]
+    return m
+
+
+def setup_model(simulation_options, animat_options, arena_options=None, **kwargs) -> Model:
+    """setup_mjcf_xml counterpart (reference mjcf.py:1174-1512): read the animat SDF named by the options and
+    compile it; a flat arena with ``ground_height`` becomes the collision plane."""
+    sdf = ModelSDF.read(animat_options.sdf)[0]
+    plane = arena_options is not None and getattr(arena_options, 'ground_height', None) is not None
+    mujoco_kw = dict(getattr(animat_options, 'mujoco', {}) or {})
+    return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options,
+                     fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane, plane=plane,
+                     **{k: v for k, v in mujoco_kw.items() if k in ('solref', 'solimp', 'friction')}, **kwargs)

@@ -54,12 +54,13 @@ class Simulation:
 
     @classmethod
     def from_sdf(cls, simulation_options, animat_options, arena_options, **kwargs):
-        """From SDF (reference simulation.py:96-124).  The SDF -> model compiler is the next row of the
-        scope table; pass a pre-built model as ``model=`` meanwhile."""
+        """From SDF (reference simulation.py:96-124): compiles ``animat_options.sdf`` with
+        :func:`~farms_mujoco_amd.simulation.mjcf.setup_model`, or takes a pre-built ``model=``."""
         model = kwargs.pop('model', None)
-        if model is None:
-            raise NotImplementedError('SDF -> model compilation is not part of the hot path yet; pass model=')
         extract_sub_dict(kwargs, ('spawn_position', 'spawn_rotation', 'save_mjcf', 'use_particles'))
+        if model is None:       # setup_mjcf_xml role (reference simulation.py:105-116)
+            from .mjcf import setup_model
+            model = setup_model(simulation_options, animat_options, arena_options)
         callbacks = kwargs.pop('callbacks', [])
         water = getattr(arena_options, 'water', None)
         if water is not None and water.height is not None and (water.drag or water.sph) \

@@ -180,3 +180,49 @@ def test_physics2data_operator_units(oracle):
     assert _relerr(sim.task.data.sensors.links.array[1].cpu().numpy(), links) < 1e-6
     assert _relerr(sim.task.data.sensors.joints.array[1].cpu().numpy(), joints) < 1e-6
     assert float(sim.task.data.sensors.links.array[0].abs().max()) == 0.0      # other ring rows untouched
+
+
+def test_from_sdf_end_to_end(oracle, tmp_path):
+    """Simulation.from_sdf on a real SDF file (reference simulation.py:96-124 -> setup_mjcf_xml): compile, swim 150
+    fused iterations with the host-callback-free fast path, compare with the oracle."""
+    import torch
+    from test_sdf_compiler import SDF, _options
+    from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, WaterOptions
+    from farms_mujoco_amd.control import WaveController
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    p = tmp_path/'swimmer.sdf'; p.write_text(SDF)
+    ao = _options(str(p))
+    n, T = 8, 150
+    psi = np.linspace(0, 5, n)
+    opts = SimulationOptions(timestep=1e-3, n_iterations=T)
+    from farms_mujoco_amd.simulation.mjcf import setup_model
+    m = setup_model(opts, ao, ArenaOptions())
+    sim = Simulation.from_sdf(opts, ao, ArenaOptions(water=WaterOptions(height=0.5)), n_envs=n, buffer_size=T,
+                              controller=_SdfWave(m, psi))
+    sim.reset()
+    m = sim.physics.model
+    assert m.body_names[1] == 'swimmer' and sim.task.base_link == 'swimmer'
+    st = _oracle_initial_state(oracle, sim, m)
+    swim, water = _swim_water(sim)
+    c = sim.task._controller
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=T, controller=1,
+                           wave=dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
+                                     env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency))
+    assert int(sim.physics.data.status.abs().sum()) == 0
+    assert _relerr(sim.physics.data.qpos.cpu().numpy(), ref['qpos']) < 1e-4
+    assert _relerr(sim.task.data.sensors.links.array.cpu().numpy(), ref['links']) < 2e-4
+    assert _relerr(sim.task.data.sensors.xfrc.array.cpu().numpy(), ref['xfrc']) < 1e-3
+
+
+def _SdfWave(m, psi):
+    """Wave controller on every position actuator of an arbitrary model (joint names are not 'joint_body_*')."""
+    import torch
+    from farms_mujoco_amd.control import WaveController
+    c = WaveController(m, psi, frequency=1.5)
+    amp = np.array([0.25 if t == 'position' else 0.0 for t in m.actuator_tags])
+    lag = np.array([0.8*m.actuator_jntid[a] for a in range(m.nu)])
+    c.amplitude = torch.as_tensor(amp, dtype=torch.float32, device='cuda:0')
+    c.phase_lag = torch.as_tensor(lag, dtype=torch.float32, device='cuda:0')
+    return c
