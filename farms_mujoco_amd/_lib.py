@@ -56,6 +56,7 @@ class CFusedArgs(ctypes.Structure):
                 ('do_readout', ctypes.c_int32), ('do_drag', ctypes.c_int32), ('controller', ctypes.c_int32),
                 ('ctrl_step_stride', ctypes.c_int64), ('row_stride_links', ctypes.c_int64),
                 ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
+                ('row_stride_contacts', ctypes.c_int64),
                 ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave)]
 
 

@@ -93,7 +93,8 @@ struct StepArgs {
   float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
   float* qacc_warmstart; float* contact; int* ncon; float* contacts_rows; float inv_newtons;
   int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
-  long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc;
+  long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc, row_stride_contacts;
+  int n_contact_rows, n_pairs; const int* geom_sensor; const int* pairs;
   float* links; float* joints; float* xfrc; float* xfrc_applied_out;
   // water / units
   float surface, viscosity, wvx, wvy, wvz, wgravity; int use_buoyancy;
@@ -532,6 +533,43 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
   *kimp = K * imp; *bb = B;
 }
 
+// One contact-sensor row (reference sensors.pyx:20-137,158-182): accumulate every contact whose keys hit `row`.
+// Contact records: pos(3) frame(9) force(3: normal,t1,t2) geom2 bits.  geom1 is always the plane here, which is
+// never a sensor key of its own, so of the four reference keys only (g2,-1,+1) and (g1,g2,-1) can match.
+__device__ __forceinline__ void contact_row(const float* C, int nc, int row, const int* geom_sensor, int n_pairs, const int* pairs,
+                                            float inv_newtons, float inv_meters, float* out) {
+  float acc[12]; float norm_sum = 0.f;
+#pragma unroll
+  for (int k = 0; k < 12; k++) acc[k] = 0.f;
+  for (int c = 0; c < nc; c++) {
+    const float* ct = C + c * 16;
+    const int g2 = __float_as_int(ct[15]);
+    for (int key = 0; key < 2; key++) {
+      int sign = 0;
+      if (key == 0) { if (geom_sensor[g2] == row) sign = +1; }
+      else { for (int p = 0; p < n_pairs; p++) if (pairs[3 * p + 2] == row && pairs[3 * p + 1] == g2) sign = -1; }
+      if (!sign) continue;
+      float tot[3];
+#pragma unroll
+      for (int i = 0; i < 3; i++) {                                            // store_forces, sensors.pyx:33-52
+        const float reaction = sign * ct[12] * ct[3 + i];
+        const float friction = sign * ct[13] * ct[6 + i] + sign * ct[14] * ct[9 + i];
+        tot[i] = reaction + friction;
+        acc[FMJ_CONTACT_REACTION + i] += reaction; acc[FMJ_CONTACT_FRICTION + i] += friction; acc[FMJ_CONTACT_TOTAL + i] += tot[i];
+      }
+      const float nrm = sqrtf(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
+#pragma unroll
+      for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] += nrm * ct[i];
+      norm_sum += nrm;
+    }
+  }
+  if (norm_sum > 0.f) { for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] /= norm_sum; }     // sensors.pyx:85-88
+#pragma unroll
+  for (int k = 0; k < 9; k++) out[k] = acc[k] * inv_newtons;                                          // :99-107
+#pragma unroll
+  for (int k = 9; k < 12; k++) out[k] = acc[k] * inv_meters;                                          // :108-110
+}
+
 // Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
 // forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
 // every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
@@ -626,6 +664,11 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     if (lane < 8) VT[lane] = 0.f;
     if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
   }
+  int cy_ncon = 0;                                  // contacts of the last forward pass (records incl. forces stay in CT)
+  if (CONS && FUSED && A.contacts_rows) {
+    cy_ncon = A.ncon[env];
+    for (int i = lane; i < cy_ncon * 16; i += 64) CT[i] = A.contact[(size_t)env * M.max_contacts * 16 + i];
+  }
   float cy_limfrc = 0.f;                            // carried joint-limit force of this dof's joint (physics.py:484-487)
   if (CONS && FUSED && isd) { const int4 da0 = DTABI(dl, 2); if (DTAB(dl, 1).w != 0.f) cy_limfrc = A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
   float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
@@ -682,6 +725,13 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
                           mk3(c2.z, c2.w, c3.x), mk3(c3.y, c3.z, c3.w), xf);
     }
     STAMP(0);   // emit links + drag
+    if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list
+      const int index = it % A.buffer_size;
+      for (int row = lane; row < A.n_contact_rows; row += 64)
+        contact_row(CT, cy_ncon, row, A.geom_sensor, A.n_pairs, A.pairs, A.inv_newtons, A.inv_meters,
+                    A.contacts_rows + ((size_t)index * A.row_stride_contacts + ((size_t)env * A.n_contact_rows + row) * FMJ_CONTACT_SIZE));
+      WSYNC();
+    }
     // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
     if (FUSED && A.do_readout) {
       const int4 di = DTABI(dlo, 0);
@@ -1240,16 +1290,19 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         if (act_lo) lf += EP[e_lo * 8 + 4];
         if (act_hi) lf += EP[e_hi * 8 + 4];
         cy_limfrc = lf * A.inv_torques;
+        cy_ncon = ncon;
+        WSYNC();
+        for (int c = lane; c < ncon; c += 64) {                   // complete the LDS records: force(3) + geom2 id
+          const float* ep = EP + (nlim + 4 * c) * 8;
+          const float f0 = ep[4], f1 = ep[12], f2 = ep[20], f3 = ep[28], mu = ep[7];
+          float* ct = CT + c * 16;
+          const float g2 = ct[14];
+          ct[12] = f0 + f1 + f2 + f3; ct[13] = mu * (f0 - f1); ct[14] = mu * (f2 - f3); ct[15] = g2;
+        }
+        WSYNC();
         if (last && d_scalar) A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z + 2] = lf;
         if (last) {
-          for (int c = lane; c < ncon; c += 64) {
-            const float* ep = EP + (nlim + 4 * c) * 8;
-            const float f0 = ep[4], f1 = ep[12], f2 = ep[20], f3 = ep[28], mu = ep[7];
-            const float* ct = CT + c * 16;
-            float* o = A.contact + ((size_t)env * M.max_contacts + c) * 16;
-            *(float4*)(o) = *(const float4*)(ct); *(float4*)(o + 4) = *(const float4*)(ct + 4); *(float4*)(o + 8) = *(const float4*)(ct + 8);
-            *(float4*)(o + 12) = make_float4(f0 + f1 + f2 + f3, mu * (f0 - f1), mu * (f2 - f3), ct[14]);
-          }
+          for (int i = lane; i < ncon * 16; i += 64) A.contact[(size_t)env * M.max_contacts * 16 + i] = CT[i];
           if (lane == 0) A.ncon[env] = ncon;
         }
       }
@@ -1397,40 +1450,9 @@ __global__ void __launch_bounds__(64) fmj_contacts2data_kernel(const DevModel M,
   const int env = blockIdx.x;
   const int nc = A.ncon[env];
   const float* C = A.contact + (size_t)env * M.max_contacts * 16;
-  for (int row = threadIdx.x; row < n_rows; row += 64) {
-    float acc[12]; float norm_sum = 0.f;
-#pragma unroll
-    for (int k = 0; k < 12; k++) acc[k] = 0.f;
-    for (int c = 0; c < nc; c++) {
-      const float* ct = C + c * 16;
-      const int g2 = __float_as_int(ct[15]), g1 = -2;      // geom1 = the plane: not a sensor key in this subset
-      (void)g1;
-      for (int key = 0; key < 2; key++) {
-        int sign = 0;
-        if (key == 0) { if (geom_sensor[g2] == row) sign = +1; }                 // (g2, -1) -> +1
-        else { for (int p = 0; p < n_pairs; p++) if (pairs[3 * p + 2] == row && pairs[3 * p + 1] == g2) sign = -1; }   // (g1, g2) -> -1
-        if (!sign) continue;
-        float tot[3];
-#pragma unroll
-        for (int i = 0; i < 3; i++) {                                            // store_forces, sensors.pyx:33-52
-          const float reaction = sign * ct[12] * ct[3 + i];
-          const float friction = sign * ct[13] * ct[6 + i] + sign * ct[14] * ct[9 + i];
-          tot[i] = reaction + friction;
-          acc[FMJ_CONTACT_REACTION + i] += reaction; acc[FMJ_CONTACT_FRICTION + i] += friction; acc[FMJ_CONTACT_TOTAL + i] += tot[i];
-        }
-        const float nrm = sqrtf(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
-#pragma unroll
-        for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] += nrm * ct[i];
-        norm_sum += nrm;
-      }
-    }
-    if (norm_sum > 0.f) { for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] /= norm_sum; }     // sensors.pyx:85-88
-    float* out = A.contacts_rows + ((size_t)env * n_rows + row) * FMJ_CONTACT_SIZE;
-#pragma unroll
-    for (int k = 0; k < 9; k++) out[k] = acc[k] * A.inv_newtons;                                       // :99-107
-#pragma unroll
-    for (int k = 9; k < 12; k++) out[k] = acc[k] * A.inv_meters;                                       // :108-110
-  }
+  for (int row = threadIdx.x; row < n_rows; row += 64)
+    contact_row(C, nc, row, geom_sensor, n_pairs, pairs, A.inv_newtons, A.inv_meters,
+                A.contacts_rows + ((size_t)env * n_rows + row) * FMJ_CONTACT_SIZE);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1868,6 +1890,11 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   A.do_drag = a->do_drag; A.controller = a->controller; A.ctrl_step_stride = a->ctrl_step_stride;
   A.row_stride_links = a->row_stride_links; A.row_stride_joints = a->row_stride_joints; A.row_stride_xfrc = a->row_stride_xfrc;
   A.links = a->rows_base.links; A.joints = a->rows_base.joints; A.xfrc = a->rows_base.xfrc;
+  if (a->rows_base.contacts && a->do_readout) {
+    if (!c->dm.cons || !c->d_geom_sensor) return set_err(FMJ_ERR_ARG, "fmj_step_fused: contact rows need a model with collision geoms and fmj_set_contact_maps");
+    A.contacts_rows = a->rows_base.contacts; A.row_stride_contacts = a->row_stride_contacts;
+    A.n_contact_rows = c->n_contact_rows; A.n_pairs = c->n_pairs; A.geom_sensor = c->d_geom_sensor; A.pairs = c->d_pairs;
+  }
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
   HIP_TRY(hipSetDevice(c->device));

@@ -98,6 +98,9 @@ class Simulation:
         a.row_stride_links = sens.links.array.stride(0)
         a.row_stride_joints = sens.joints.array.stride(0)
         a.row_stride_xfrc = sens.xfrc.array.stride(0)
+        if sens.contacts.names:
+            a.rows_base.contacts = sens.contacts.array.data_ptr()
+            a.row_stride_contacts = sens.contacts.array.stride(0)
         swim = [cb for cb in task._callbacks if isinstance(cb, SwimmingCallback)]
         a.do_drag = int(bool(swim) and swim[0].handler.drag)
         if swim:

@@ -190,5 +190,4 @@ class ExperimentTask:
         sequence can run inside one launch (fmj_step_fused)."""
         cbs_ok = all(getattr(cb, 'fusable', False) for cb in self._callbacks)
         ctl_ok = self._controller is None or getattr(self._controller, 'fusable', False)
-        no_contact_rows = self.data is None or not self.data.sensors.contacts.names    # contact rows: operator path
-        return cbs_ok and ctl_ok and self.substeps == 1 and no_contact_rows
+        return cbs_ok and ctl_ok and self.substeps == 1

@@ -290,6 +290,8 @@ typedef struct fmj_fused_args {
   int32_t controller;       /* 0 tape, 1 wave */
   int64_t ctrl_step_stride;
   int64_t row_stride_links, row_stride_joints, row_stride_xfrc;
+  int64_t row_stride_contacts;  /* used when rows_base.contacts != NULL: contact rows are written too
+                                   (needs fmj_set_contact_maps) */
   fmj_rows rows_base;
   fmj_water water;
   fmj_units units;

@@ -185,3 +185,34 @@ def test_contacts2data_rows(oracle):
         assert np.allclose(got[e], want, rtol=1e-5, atol=1e-7)
     assert np.abs(got[..., 2]).max() > 0            # some vertical reaction force was logged
     assert float(data.sensors.contacts.array[0].abs().max()) == 0.0
+
+
+def test_fused_walk_with_contact_rows(oracle):
+    """Config 4 through the Simulation layer: fused launches log link, joint AND contact rows; they equal the
+    operator-by-operator path (physics2data + cycontacts2data + fmj_step) row for row."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    from farms_mujoco_amd.control import AnimatController, ControlType
+    m = _walker()
+    n, T = 4, 60
+    pairs = [(b, '') for b in m.body_names[1:] if b.endswith('_3') or b.startswith('body_')]
+
+    def make():
+        data = AnimatData(m.timestep, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+        sim = Simulation(m, m.body_names[1], SimulationOptions(timestep=m.timestep, n_iterations=T), n_envs=n, data=data,
+                         buffer_size=T)
+        sim.reset()
+        return sim
+    sim_f, sim_u = make(), make()
+    assert sim_f.task.fusable()
+    sim_f.run(fused=True, chunk=25)
+    sim_u.run(fused=False)
+    torch.cuda.synchronize()
+    for k in ('links', 'joints', 'contacts'):
+        a = getattr(sim_f.task.data.sensors, k).array.cpu().numpy(); b = getattr(sim_u.task.data.sensors, k).array.cpu().numpy()
+        assert np.array_equal(a, b), k                   # same device functions, same order of operations: bitwise
+    c = sim_f.task.data.sensors.contacts.array.cpu().numpy()
+    assert np.abs(c[T - 1][..., 2]).max() > 0.05          # the feet carry weight at the end (reaction z)
+    assert np.array_equal(sim_f.physics.data.qpos.cpu().numpy(), sim_u.physics.data.qpos.cpu().numpy())
