@@ -34,18 +34,34 @@ def algorithmic_bytes_per_env_step(m):
     return b_core + b_log
 
 
-def build_sim(n_envs, n_iterations, chunk, env_offset, device):
+def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', morphology='salamander33'):
+    """Fused simulation of one morphology.  workload 'swim' = BASELINE configs[1] (water, drag + buoyancy, no contact);
+    'walk' = configs[3] (plane contacts + joint limits, PGS, no water)."""
     import torch
-    from farms_mujoco_amd.model import salamander33, synthetic_batch
+    import farms_mujoco_amd.model as mm
     from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
     from farms_mujoco_amd.control import WaveController
     from farms_mujoco_amd.simulation.simulation import Simulation
-    m = salamander33()
-    qpos, qvel, psi = synthetic_batch(m, n_envs, seed=0, env_offset=env_offset)
+    from farms_mujoco_amd.data import AnimatData
+    if workload == 'walk':
+        m = mm.salamander33(contacts=True, limits=True, spawn_z=0.045)
+    else:
+        m = getattr(mm, morphology)()
+    qpos, qvel, psi = mm.synthetic_batch(m, n_envs, seed=0, env_offset=env_offset)
     opts = SimulationOptions(timestep=m.timestep, n_iterations=n_iterations)
-    arena = ArenaOptions(water=WaterOptions(height=0.0, drag=True, buoyancy=True, viscosity=1.0))
+    ctl = WaveController(m, psi, device=device)
+    kw = {}
+    if workload == 'walk':
+        arena = ArenaOptions(water=WaterOptions(height=None, drag=False), ground_height=0.0)
+        amp, lag = mm.trot_controller_params(m)
+        ctl.amplitude = torch.as_tensor(amp, dtype=torch.float32, device=device)
+        ctl.phase_lag = torch.as_tensor(lag, dtype=torch.float32, device=device)
+        pairs = [(b, '') for b in m.body_names[1:] if b.endswith('_3') or b.startswith('body_')]
+        kw['data'] = AnimatData(m.timestep, chunk, n_envs, m.body_names[1:], m.hinge_joint_names(), contacts=pairs, device=device)
+    else:
+        arena = ArenaOptions(water=WaterOptions(height=0.0, drag=True, buoyancy=True, viscosity=1.0))
     sim = Simulation.from_sdf(opts, AnimatOptions.from_model(m), arena, model=m, n_envs=n_envs, device=device,
-                              controller=WaveController(m, psi, device=device), buffer_size=chunk)
+                              controller=ctl, buffer_size=chunk, **kw)
     sim.reset()
     d = sim.physics.data
     d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32)
@@ -103,6 +119,8 @@ def main():
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--chunk', type=int, default=100, help='steps per fused launch (= ring-buffer length)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed'],
+                    help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede')
     ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --same-device rehearses the N>1 path on a 1-GPU box")
     ap.add_argument('--same-device', action='store_true', help='all ranks use cuda:0 (rehearsal only)')
     args = ap.parse_args()
@@ -129,7 +147,13 @@ def main():
     n_envs = args.envs_per_gpu
     K, W = args.steps, args.warmup
     chunk = max(1, min(args.chunk, K))
-    sim, m, _ = build_sim(n_envs, K + W + chunk, chunk, env_offset=rank*n_envs, device=device)
+    if args.workload == 'mixed':      # bucketed batching: half the envs are eels, half centipedes, no padding
+        sims = [build_sim(n_envs//2, K + W + chunk, chunk, rank*n_envs, device, morphology='eel')[0],
+                build_sim(n_envs - n_envs//2, K + W + chunk, chunk, rank*n_envs + n_envs//2, device, morphology='centipede')[0]]
+        sim, m = sims[0], sims[0].physics.model
+    else:
+        sim, m, _ = build_sim(n_envs, K + W + chunk, chunk, env_offset=rank*n_envs, device=device, workload=args.workload)
+        sims = [sim]
 
     def run(n):
         done, evs = 0, []
@@ -137,7 +161,8 @@ def main():
             c = min(chunk, n - done)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            sim.step_fused(c)
+            for s_ in sims:
+                s_.step_fused(c)
             e1.record()
             evs.append((e0, e1, c))
             done += c
@@ -157,7 +182,8 @@ def main():
     dt = time.perf_counter() - t0
     from farms_mujoco_amd.sharding import max_over_ranks
     dt = max_over_ranks(dt, device=device if args.dist_backend == 'nccl' else None)
-    sim.physics.check_invalid_state()
+    for s_ in sims:
+        s_.physics.check_invalid_state()
 
     if rank == 0:
         # dominant kernel = the fused step kernel; HIP events on the launch stream around every launch
@@ -181,9 +207,13 @@ def main():
             'value': n_envs*world*K/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'ms_per_step': dt/K*1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
-            'config': {'workload': f'BASELINE configs[1]: {n_envs}x salamander-33 swimming per GPU (nbody={m.nbody}, '
-                                   f'nv={m.nv}, nu={m.nu}), drag+buoyancy, no contact, h=1e-3, travelling-wave position '
-                                   f'control, sensor rows logged every step',
+            'config': {'workload': {'swim': f'BASELINE configs[1]: {n_envs}x salamander-33 swimming per GPU (nbody={m.nbody}, '
+                                            f'nv={m.nv}, nu={m.nu}), drag+buoyancy, no contact, h=1e-3, travelling-wave position '
+                                            f'control, sensor rows logged every step',
+                                    'walk': f'BASELINE configs[3]: {n_envs}x salamander-33 walking on a plane per GPU, joint limits + '
+                                            f'sphere/capsule contacts, pyramidal cone, PGS <= 50 sweeps, link/joint/contact rows logged',
+                                    'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
+                                             f'GPU, one bucket per morphology'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',
                        'lds_bytes_per_env': info['lds_bytes_per_env']},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
@@ -194,7 +224,7 @@ def main():
                          'algorithmic_bytes_per_env_step': b_step,
                          'note': 'VALU-issue-bound tree recursions (profiles/r01_v5_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:
                 out['cpu_baseline'] = cpu_baseline(m, sim)
             except Exception as e:      # the baseline is reported, never required

@@ -726,3 +726,17 @@ def synthetic_batch(m: Model, n_envs: int, seed: int = 0, env_offset: int = 0, p
         psi[e] = rng.uniform(0, 2*np.pi)
     qvel = np.zeros((n_envs, m.nv))
     return qpos, qvel, psi
+
+
+def trot_controller_params(m: Model, spine_amplitude: float = 0.2, limb_amplitude: float = 0.3):
+    """Per-actuator amplitude / phase lag of a trot-like gait for the walking config (BASELINE configs[3]): axial
+    travelling wave plus shoulder-pitch swing with diagonal limb pairs in phase (front-L/hind-R vs front-R/hind-L)."""
+    amp, lag = wave_controller_params(m, spine_amplitude, 1.0)
+    for a in range(m.nu):
+        if m.actuator_tags[a] != 'position':
+            continue
+        name = m.joint_names[int(m.actuator_jntid[a])]
+        if name.startswith('joint_leg_') and name.endswith('_1'):
+            amp[a] = limb_amplitude
+            lag[a] = 0.0 if ('front_L' in name or 'hind_R' in name) else np.pi
+    return amp, lag
