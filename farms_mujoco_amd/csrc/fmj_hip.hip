@@ -117,6 +117,7 @@ struct fmj_ctx {
   int nbody, nv, nu, njnt;
   std::vector<int> jnt_dofadr, jnt_type;
   int ngeom, n_contact_rows, n_pairs; std::vector<int> geom_sensor, geom_is_plane; int* d_geom_sensor; int* d_pairs;
+  int* d_links_body; int* d_joints_dof;      // row -> body / dof maps of the standalone readout operator
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -1501,6 +1502,18 @@ static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) 
   return FMJ_OK;
 }
 
+// device copies of the row -> body / dof maps used by fmj_physics2data (rebuilt from the host mirrors; tiny)
+static int sync_readout_maps(fmj_ctx* c) {
+  std::vector<int> lb(c->dm.n_links ? c->dm.n_links : 1, 1), jd(c->dm.n_joints ? c->dm.n_joints : 1, 0);
+  for (int b = 1; b < c->nbody; b++) if (c->h_b_info2[4 * b + 2] >= 0) lb[c->h_b_info2[4 * b + 2]] = b;
+  for (int dd = 0; dd < c->nv; dd++) if (c->h_d_info[4 * dd + 3] >= 0) jd[c->h_d_info[4 * dd + 3]] = dd;
+  const int* a = nullptr; const int* b2 = nullptr;
+  int rc;
+  if ((rc = upload(c, lb, &a)) || (rc = upload(c, jd, &b2))) return rc;
+  c->d_links_body = (int*)a; c->d_joints_dof = (int*)b2;
+  return FMJ_OK;
+}
+
 // re-pack the host-mutable int fields (link row / swim slot / joint row) and refresh the device tables
 static int sync_tables(fmj_ctx* c) {
   for (int b = 0; b < 64; b++) c->h_btab[b * BT_STRIDE + 8] = make_float4(ibits(c->h_b_info2[4 * b]), ibits(c->h_b_info2[4 * b + 1]), ibits(c->h_b_info2[4 * b + 2]), ibits(c->h_b_info2[4 * b + 3]));
@@ -1590,7 +1603,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
 
   fmj_ctx* c = new fmj_ctx();
   c->device = device; c->n_envs = n_envs; c->nbody = nb; c->nv = nv; c->nu = nu; c->njnt = nj;
-  c->d_btab = nullptr; c->d_dtab = nullptr;
+  c->d_btab = nullptr; c->d_dtab = nullptr; c->d_links_body = nullptr; c->d_joints_dof = nullptr;
   DevModel& D = c->dm;
   memset(&D, 0, sizeof D);
   D.nbody = nb; D.nv = nv; D.nq = nq; D.nu = nu; D.njnt = nj; D.nM = m->nM;
@@ -1830,6 +1843,7 @@ int fmj_set_readout_maps(fmj_ctx* c, int32_t n_links, const int32_t* links_body,
   }
   { int rc2 = sync_tables(c); if (rc2) return rc2; }
   c->dm.n_links = n_links; c->dm.n_joints = n_joints;
+  { int rc3 = sync_readout_maps(c); if (rc3) return rc3; }
   if (c->dm.n_xfrc < n_links) c->dm.n_xfrc = n_links;
   return FMJ_OK;
 }
@@ -1918,17 +1932,8 @@ int fmj_physics2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const 
   StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
   A.links = rows->links; A.joints = rows->joints; fill_units(&A, units);
   HIP_TRY(hipSetDevice(c->device));
-  // device copies of the row -> body / dof maps (rebuilt from the host mirrors; tiny)
-  std::vector<int> lb(c->dm.n_links ? c->dm.n_links : 1, 1), jd(c->dm.n_joints ? c->dm.n_joints : 1, 0);
-  for (int b = 1; b < c->nbody; b++) if (c->h_b_info2[4 * b + 2] >= 0) lb[c->h_b_info2[4 * b + 2]] = b;
-  for (int dd = 0; dd < c->nv; dd++) if (c->h_d_info[4 * dd + 3] >= 0) jd[c->h_d_info[4 * dd + 3]] = dd;
-  static thread_local int* d_lb = nullptr; static thread_local int* d_jd = nullptr; static thread_local size_t cap = 0;
-  size_t need = lb.size() + jd.size();
-  if (need > cap) { if (d_lb) (void)hipFree(d_lb); HIP_TRY(hipMalloc((void**)&d_lb, need * sizeof(int))); cap = need; }
-  d_jd = d_lb + lb.size();
-  HIP_TRY(hipMemcpyAsync(d_lb, lb.data(), lb.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
-  HIP_TRY(hipMemcpyAsync(d_jd, jd.data(), jd.size() * sizeof(int), hipMemcpyHostToDevice, (hipStream_t)stream));
-  hipLaunchKernelGGL(fmj_physics2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)links_only, (const int*)d_lb, (const int*)d_jd);
+  if (!c->d_links_body || !c->d_joints_dof) { int rc2 = sync_readout_maps(c); if (rc2) return rc2; }
+  hipLaunchKernelGGL(fmj_physics2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)links_only, (const int*)c->d_links_body, (const int*)c->d_joints_dof);
   HIP_TRY(hipGetLastError());
   return FMJ_OK;
 }
