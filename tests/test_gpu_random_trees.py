@@ -1,0 +1,94 @@
+"""Generality of the HIP path: seeded random kinematic trees (branching, welded bodies, hinge + slide joints with
+off-centre anchors, rotated inertial frames, free or fixed base, spring-dampers, armature, all three actuator kinds
+with control / force limits, external forces) against the fp64 oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def random_tree(seed):
+    from farms_mujoco_amd.model import ModelBuilder, euler2quat
+    rng = np.random.default_rng(seed)
+    nb = int(rng.integers(3, 22))
+    free = bool(rng.integers(0, 2))
+    b = ModelBuilder(f'tree{seed}', timestep=1e-3, gravity=(0, 0, -9.81) if rng.integers(0, 2) else (0.5, -0.3, -9.0))
+    names = []
+
+    def inertia():
+        A = rng.normal(size=(3, 3)); S = A @ A.T*1e-4 + np.eye(3)*2e-4
+        return (S[0, 0], S[1, 1], S[2, 2], S[0, 1], S[0, 2], S[1, 2])
+    for i in range(nb):
+        name = f'b{i}'
+        mass = float(rng.uniform(0.05, 0.5))
+        kw = dict(mass=mass, ipos=rng.normal(size=3)*0.03, fullinertia=inertia())
+        if i == 0:
+            if free:
+                b.add_body(name, 'world', pos=rng.normal(size=3)*0.2, quat=euler2quat(rng.normal(size=3)), joint='free', **kw)
+            else:
+                jt = ['hinge', 'slide', None][int(rng.integers(0, 3))]
+                jkw = dict(joint=jt, axis=rng.normal(size=3), jpos=rng.normal(size=3)*0.02, damping=0.01) if jt else {}
+                b.add_body(name, 'world', pos=rng.normal(size=3)*0.2, quat=euler2quat(rng.normal(size=3)), **jkw, **kw)
+        else:
+            parent = names[int(rng.integers(max(0, i - 4), i))]
+            u = rng.random()
+            jt = 'hinge' if u < 0.7 else 'slide' if u < 0.85 else None
+            jkw = {}
+            if jt:
+                jkw = dict(joint=jt, axis=rng.normal(size=3), jpos=rng.normal(size=3)*0.03 if rng.random() < 0.5 else (0, 0, 0),
+                           damping=float(rng.choice([0.0, 2e-3, 1e-2])), stiffness=float(rng.choice([0.0, 0.0, 0.05])),
+                           armature=float(rng.choice([0.0, 1e-4])), qpos0=float(rng.choice([0.0, 0.2])))
+            b.add_body(name, parent, pos=rng.normal(size=3)*0.08, quat=euler2quat(rng.normal(size=3)*0.5), **jkw, **kw)
+        names.append(name)
+    joints = [bd.joint['name'] for bd in b.bodies[1:] if bd.joint and bd.joint['type'] != 0]
+    for jn in joints:
+        r = rng.random()
+        if r < 0.5:
+            b.add_joint_actuators(jn, kp=float(rng.uniform(0.1, 0.5)), kv=float(rng.uniform(0, 0.01)),
+                                  forcerange=(-0.2, 0.3) if rng.random() < 0.5 else None)
+        elif r < 0.75:
+            b.add_position_actuator(jn, kp=0.3)
+    if not joints and not free:
+        return None
+    return b.compile()
+
+
+@pytest.mark.parametrize('seed', range(14))
+def test_random_tree_vs_oracle(oracle, seed):
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = random_tree(seed)
+    if m is None or m.nv == 0:
+        pytest.skip('degenerate draw')
+    rng = np.random.default_rng(1000 + seed)
+    n = 6
+    qpos = np.tile(m.qpos0, (n, 1)) + rng.uniform(-0.4, 0.4, (n, m.nq))
+    for j in range(m.njnt):
+        if m.jnt_type[j] == 0:
+            a = m.jnt_qposadr[j]; q = rng.normal(size=(n, 4)); qpos[:, a+3:a+7] = q/np.linalg.norm(q, axis=1, keepdims=True)
+    qvel = rng.normal(size=(n, m.nv))*0.5
+    ctrl = rng.uniform(-0.6, 0.6, (n, max(m.nu, 1)))[:, :m.nu]
+    xf = rng.normal(size=(n, m.nbody, 6))*0.05; xf[:, 0] = 0
+    qs = np.tile(m.qpos_spring, (n, 1)) + rng.uniform(-0.1, 0.1, (n, m.nq))
+    phys = BatchedPhysics(m, n)
+    d = phys.data
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32)
+    d.qpos[:] = f32(qpos); d.qvel[:] = f32(qvel); d.xfrc_applied[:] = f32(xf); d.qpos_spring[:] = f32(qs)
+    if m.nu:
+        d.ctrl[:] = f32(ctrl)
+    r64 = lambda t: t.cpu().numpy().astype(np.float64)
+    q32, v32, c32, x32, s32 = r64(d.qpos), r64(d.qvel), r64(d.ctrl), r64(d.xfrc_applied), r64(d.qpos_spring)
+    phys.step(1)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None, qpos_spring=s32, xfrc_applied=x32)
+    assert int(d.status.abs().sum()) == 0
+
+    def err(k):
+        a = r64(getattr(d, k)); bb = ref[k]
+        return np.abs(a - bb).max()/max(np.abs(bb).max(), 1e-9)
+    for k, tol in (('xpos', 5e-6), ('xquat', 5e-6), ('xipos', 5e-6), ('sensordata', 1e-4), ('qvel', 5e-4), ('qpos', 5e-6)):
+        assert err(k) < tol, (seed, m.nbody, m.nv, k, err(k))
+    phys.step(49)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None, qpos_spring=s32, xfrc_applied=x32, n_steps=50)
+    assert err('qpos') < 2e-3, (seed, 'qpos50', err('qpos'))
