@@ -65,6 +65,10 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
+  // ---- two-envs-per-wave instantiation (fmj_dual.inc)
+  int dual_ok, dual_t0, dual_nM;       // eligible, translational dofs carried as scalars (3 with a free root), padded entry count
+  float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
+  const float4* mtab2;                 // [dual_nM] entries (i, j >= dual_t0) in the mtab format
 };
 
 
@@ -107,7 +111,7 @@ struct fmj_ctx {
   int device, n_envs;
   DevModel dm;
   std::vector<void*> allocs;
-  size_t lds_bytes;
+  size_t lds_bytes, lds_bytes_dual;
   fmj_sensor_layout_t layout;
   // host copies needed later
   std::vector<int> body_link_row, dof_joint_row, body_swim;
@@ -329,6 +333,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   LdsLayout L;
   const int nmax = nb > nv ? nb : nv;
   int o = 0;
+  // every region starts on a 16-byte boundary (float4 LDS accesses; a misaligned ds_read_b128 is split and stalls)
   L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
   L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
   L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
@@ -338,7 +343,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.QV = o; o += r4(nv);
   L.XV = o; o += r4(nv);
   L.VT = o; o += 8;
-  L.ANC = o; o += r4(nb * anc_stride) / 4;
+  L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
   L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = o;
   if (cons) {
@@ -352,6 +357,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
     L.DI = o; o += r4(nv);            // 1/D of the M factor
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
   }
+  o = r4(o);
   L.total = o;
   return L;
 }
@@ -1373,6 +1379,8 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
   }
 }
 
+#include "fmj_dual.inc"
+
 // ---------------------------------------------------------------------------------------------
 // standalone operators (same arithmetic as the fused loop; one wave per env)
 
@@ -1493,7 +1501,27 @@ static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
   if (c->dm.cons) return fused ? pick_step_kernel<true, true>(c->dm.rs) : pick_step_kernel<false, true>(c->dm.rs);
   return fused ? pick_step_kernel<true, false>(c->dm.rs) : pick_step_kernel<false, false>(c->dm.rs);
 }
+template <bool FUSED>
+static step_kernel_t pick_dual_kernel(int rs) {
+  switch (rs) {
+    case 4: return fmj_step_dual_kernel<FUSED, 4>;
+    case 8: return fmj_step_dual_kernel<FUSED, 8>;
+    case 12: return fmj_step_dual_kernel<FUSED, 12>;
+    case 16: return fmj_step_dual_kernel<FUSED, 16>;
+    case 20: return fmj_step_dual_kernel<FUSED, 20>;
+    case 24: return fmj_step_dual_kernel<FUSED, 24>;
+    case 28: return fmj_step_dual_kernel<FUSED, 28>;
+    default: return fmj_step_dual_kernel<FUSED, 32>;
+  }
+}
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
+  if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual.inc); fmj_forward keeps the single-env kernel
+    step_kernel_t k = fused ? pick_dual_kernel<true>(c->dm.rs) : pick_dual_kernel<false>(c->dm.rs);
+    hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
+    return FMJ_OK;
+  }
   if (c->dm.cons && (!A.qacc_warmstart || !A.contact || !A.ncon))
     return set_err(FMJ_ERR_ARG, "fmj_data: qacc_warmstart, contact and ncon are required for models with limits / contacts");
   hipLaunchKernelGGL(pick_kernel(c, fused), dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
@@ -1768,6 +1796,19 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
   for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; }
   UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(mtab, mtab); UP(gtab, gtab); UP(ptab, ptab);
+  {   // two envs per wave: bodies and the dofs minus a free root's translational dofs must fit 32 lanes
+    const int t0 = D.root_free ? 3 : 0;
+    const char* envv = getenv("FMJ_DUAL");
+    D.dual_t0 = t0;
+    D.dual_ok = !cons && nb <= 32 && nv - t0 <= 32 && !(envv && envv[0] == '0');
+    std::vector<float4> mtab2;
+    { int ee = 0; for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { if (i >= t0 && j >= t0) mtab2.push_back(mtab[ee]); ee++; } }
+    while (mtab2.size() % 32) mtab2.push_back(f4(0, 0, 0, 0));
+    if (mtab2.empty()) mtab2.assign(32, f4(0, 0, 0, 0));
+    D.dual_nM = (int)mtab2.size();
+    for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
+    UP(mtab2, mtab2);
+  }
   c->d_btab = (float4*)D.btab; c->d_dtab = (float4*)D.dtab;
   { std::vector<float4> empty4(ST_STRIDE, f4(0, 0, 0, 0)); UP(empty4, stab); }
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
@@ -1775,6 +1816,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
   c->lds_bytes = (size_t)L.total * sizeof(float);
+  c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
   if (c->lds_bytes > 64 * 1024) {
     hipError_t e1 = hipFuncSetAttribute((const void*)pick_kernel(c, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)pick_kernel(c, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
