@@ -220,9 +220,11 @@ def main():
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'traffic_note': 'bytes per launch, FETCH_SIZE + WRITE_SIZE as counted (profiles/), algorithmic = '
                                          f'{alg_bytes_per_launch}',
-                         'kernel': 'fmj_step_kernel<true>', 'avg_launch_ms': avg_launch_s*1e3,
+                         'kernel': ('fmj_step_dual_kernel<true, MAXD> (two envs per wave)' if info['threads_per_env'] == 32
+                                    else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
+                         'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b_step,
-                         'note': 'VALU-issue-bound tree recursions (profiles/r01_v5_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
+                         'note': 'latency/VALU-issue-bound tree recursions (profiles/r01_v6_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:

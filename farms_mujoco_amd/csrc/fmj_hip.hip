@@ -1834,7 +1834,7 @@ int fmj_get_sensor_layout(const fmj_ctx* c, fmj_sensor_layout_t* out) {
 int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threads_per_env) {
   if (!c) return set_err(FMJ_ERR_ARG, "fmj_kernel_info: NULL ctx");
   if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)c->lds_bytes;
-  if (threads_per_env) *threads_per_env = 64;
+  if (threads_per_env) *threads_per_env = c->dm.dual_ok ? 32 : 64;   // the integrating step packs two envs per wave when it can
   return FMJ_OK;
 }
 
