@@ -326,7 +326,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
   int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
-  int HM, YJ, EP, CT, XS, WW, QW, DI, PO;      // constraint path only
+  int HM, YJ, EP, CT, XS, WW, QW, DI, PO, AT, na;      // constraint path only
 };
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
                                                 int maxcon = 0, int nvs = 0) {
@@ -345,7 +345,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.VT = o; o += 8;
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
-  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = o;
+  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = L.AT = o; L.na = 0;
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
     L.YJ = o; o += r4(maxefc * nvs);  // constraint Jacobian rows J, then Y = J L^-1
@@ -356,6 +356,8 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
     L.QW = o; o += r4(nv);            // qacc_warmstart
     L.DI = o; o += r4(nv);            // 1/D of the M factor
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
+    L.na = maxefc < 64 ? maxefc : 64; // rows the explicit PGS matrix holds (one row per lane)
+    L.AT = o; o += r4(L.na * (L.na + 1) / 2);   // packed lower triangle of A + diag(R)
   }
   o = r4(o);
   L.total = o;
@@ -616,7 +618,7 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 // Diagnostic build only (-DFMJ_STAMPS): per-phase s_memtime deltas of env 0, summed over the steps of a launch,
 // written over qacc[0, :]. Never enabled in the shipped library; its numbers are shares, not run times.
 #ifdef FMJ_STAMPS
-#define NSTAMP 14
+#define NSTAMP 24
 #define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); unsigned long long t_ = __builtin_amdgcn_s_memtime(); __builtin_amdgcn_s_waitcnt(0xC07F); \
     stamp_acc[i] += (float)(t_ - stamp_prev); stamp_prev = t_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
@@ -644,7 +646,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
   float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
   float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EP = lds + LL.EP;  float* CT = lds + LL.CT;
   float* XS = lds + LL.XS;  float* WW = lds + LL.WW;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
-  float* PO = lds + LL.PO;
+  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;
   const int nvs = M.nvs;
 
   const bool isb = lane > 0 && lane < nb;
@@ -1089,6 +1091,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       }
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; }
+      STAMP(12);  // factor M + qacc_smooth
       // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
       const float4 lim = DTAB(dlo, 3);
       float dist_lo = 0.f, dist_hi = 0.f; bool act_lo = false, act_hi = false;
@@ -1152,6 +1155,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       if (ncon > M.max_contacts) { ncon = M.max_contacts; warn |= FMJ_WARN_CONTACTFULL; }
       const int nefc = nlim + 4 * ncon;
       WSYNC();
+      STAMP(13);  // limits + contacts
       // (4) Jacobian rows.  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d =
       //     cdof_lin + cdof_rot x (p - com) for the dofs on the body's chain.
       for (int i = lane; i < nefc * nvs; i += 64) YJ[i] = 0.f;
@@ -1178,6 +1182,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         }
       }
       WSYNC();
+      STAMP(14);  // J rows
       // (5) per row (lane = row): R, aref (mj_makeImpedance / mj_referenceConstraint), b = J qacc_smooth - aref,
       //     warm-start force from the previous qacc (mj_fwdConstraint)
       for (int e = lane; e < nefc; e += 64) {
@@ -1218,60 +1223,159 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       }
       WSYNC();
       for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f; }
-      // (6) Y = J L^-1 (lane = row): y_a -= L[i][a] y_i for every dof i (leaves first) and ancestor a
+      STAMP(15);  // row params
+      // (6) Y = J L^-1 (lane = row): y_a -= L[i][a] y_i for every dof i (leaves first) and ancestor a.
+      //     The ancestors of i are walked once (uniform), then the row's loads, FMAs and stores go out in batches.
       for (int i = nv - 1; i >= 1; i--) {
         const int depi = __builtin_amdgcn_readlane(ddepth, i);
-        for (int e = lane; e < nefc; e += 64) {
-          float* y = YJ + e * nvs;
-          const float yi = y[i];
-          int a = i;
-          for (int dd = depi - 1; dd >= 0; dd--) {
-            a = __builtin_amdgcn_readlane(dparent, a);          // uniform parent walk: ancestor at depth dd
-            y[a] = fmaf(-HM[i * RS + dd], yi, y[a]);
+        if (depi == 0) continue;
+        {   // nothing to do when no row has weight on dof i (rows beyond the first 64 are checked per batch below)
+          bool nz = false;
+          for (int e = lane; e < nefc; e += 64) nz |= YJ[e * nvs + i] != 0.f;
+          if (!__any(nz)) continue;
+        }
+        int anc[MAXD];
+        { int a = i;
+#pragma unroll
+          for (int dd = MAXD - 1; dd >= 0; dd--) { if (dd < depi) a = __builtin_amdgcn_readlane(dparent, a); anc[dd] = a; } }
+        for (int e0 = 0; e0 < nefc; e0 += 64) {
+          const int e = e0 + lane;
+          float* y = YJ + (e < nefc ? e : 0) * nvs;
+          const float yi = e < nefc ? y[i] : 0.f;
+          if (!__any(yi != 0.f)) continue;
+          float yv[MAXD];
+#pragma unroll
+          for (int dd = 0; dd < MAXD; dd++) yv[dd] = y[anc[dd]];
+#pragma unroll
+          for (int g = 0; g < MAXD / 4; g++) {
+            const float4 l4 = *(const float4*)(HM + i * RS + 4 * g);
+            yv[4 * g + 0] = fmaf(4 * g + 0 < depi ? -l4.x : 0.f, yi, yv[4 * g + 0]);
+            yv[4 * g + 1] = fmaf(4 * g + 1 < depi ? -l4.y : 0.f, yi, yv[4 * g + 1]);
+            yv[4 * g + 2] = fmaf(4 * g + 2 < depi ? -l4.z : 0.f, yi, yv[4 * g + 2]);
+            yv[4 * g + 3] = fmaf(4 * g + 3 < depi ? -l4.w : 0.f, yi, yv[4 * g + 3]);
+          }
+          if (e < nefc) {
+#pragma unroll
+            for (int dd = 0; dd < MAXD; dd++) if (dd < depi) y[anc[dd]] = yv[dd];
           }
         }
       }
       WSYNC();
-      // (7) diagA, w0 = D^-1 Y' f, dual cost of the warm start; zero it if it is worse than f = 0
-      for (int e = lane; e < nefc; e += 64) {
-        const float* y = YJ + e * nvs; float s = 0.f;
-        for (int d = 0; d < nv; d++) s = fmaf(y[d] * y[d], DI[d], s);
-        const float da = s + EP[e * 8 + 2];
-        EP[e * 8 + 5] = da; EP[e * 8] = 1.0f / da;                   // pos is no longer needed: slot 0 = 1/A_ee
-      }
+      STAMP(16);  // Y
       float w = 0.f;
-      if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], EP[e * 8 + 4], w); w *= dinv_m; WW[lane] = w; }
-      WSYNC();
-      {
-        float cost = 0.f;
+      if (nefc <= LL.na) {
+        // (7a) explicit A = Y D^-1 Y' + diag(R), packed lower triangle in LDS, lane = row; 4 columns per pass
+        const bool isr = lane < nefc;
+        const int je = isr ? lane : 0;
+        const int tri = je * (je + 1) / 2;
+        {
+          const float* ye = YJ + je * nvs;
+          for (int f0 = 0; f0 < nefc; f0 += 4) {
+            const int r1 = f0 + 1 < nefc ? f0 + 1 : f0, r2 = f0 + 2 < nefc ? f0 + 2 : f0, r3 = f0 + 3 < nefc ? f0 + 3 : f0;
+            const float* y0 = YJ + f0 * nvs; const float* y1 = YJ + r1 * nvs; const float* y2 = YJ + r2 * nvs; const float* y3 = YJ + r3 * nvs;
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+            for (int d = 0; d < nv; d++) {
+              const float t = ye[d] * DI[d];
+              a0 = fmaf(t, y0[d], a0); a1 = fmaf(t, y1[d], a1); a2 = fmaf(t, y2[d], a2); a3 = fmaf(t, y3[d], a3);
+            }
+            if (isr) {
+              const float Rj = EP[je * 8 + 2];
+              if (f0 <= je)                   AT[tri + f0]     = a0 + (f0 == je ? Rj : 0.f);
+              if (f0 + 1 <= je)               AT[tri + f0 + 1] = a1 + (f0 + 1 == je ? Rj : 0.f);
+              if (f0 + 2 <= je)               AT[tri + f0 + 2] = a2 + (f0 + 2 == je ? Rj : 0.f);
+              if (f0 + 3 <= je)               AT[tri + f0 + 3] = a3 + (f0 + 3 == je ? Rj : 0.f);
+            }
+          }
+        }
+        WSYNC();
+        STAMP(17);  // A
+        // warm start: keep it only if its dual cost beats f = 0 (mj_fwdConstraint)
+        float fj = isr ? EP[je * 8 + 4] : 0.f;
+        const float bj = isr ? EP[je * 8 + 3] : 0.f;
+        const float diag = isr ? AT[tri + je] : 1.f;
+        const float ainv = 1.0f / diag;
+        float afj = 0.f;
+        for (int k = 0; k < nefc; k++) {
+          const float akj = AT[k <= je ? tri + k : k * (k + 1) / 2 + je];
+          afj = fmaf(isr ? akj : 0.f, bcast(fj, k), afj);
+        }
+        {
+          const float cost = wave_sum_fast(fj * (0.5f * afj + bj));
+          if (cost > 0.f) { fj = 0.f; afj = 0.f; }
+        }
+        float res = bj + afj;                                        // residual of row j: b + (A + R) f
+        STAMP(18);  // warm start
+        // (8a) PGS on the explicit matrix.  Every lane keeps the update its own row would make from its current
+        //      residual (delta_j = max(-f_j, -res_j / A_jj), reverted if it would raise the cost by > 1e-10); row e's
+        //      turn is then one v_readlane of that value and one FMA on every residual: no reduction, no SGPR math.
+        //      Column e of the packed triangle for row j sits at max(tri(j) + e, tri(e) + j); fetched two rows ahead.
+        const float hdiag = 0.5f * diag;
+        const float nainv = -ainv;
+        for (int itp = 0; itp < M.solver_iterations; itp++) {
+          float imp = 0.f;
+          float acol = AT[tri], acol1 = AT[nefc > 1 ? max(tri + 1, 1 + je) : tri];
+          int tcol = 1;                                               // tri(e + 1)
+          for (int e = 0; e < nefc; e++) {
+            tcol += e + 2;                                            // tri(e + 2)
+            const float acol2 = AT[e + 2 < nefc ? max(tri + e + 2, tcol + je) : tri];
+            const float cand = fmaxf(-fj, res * nainv);
+            const float t = fmaf(hdiag, cand, res);
+            const float delta_j = (cand * t > 1e-10f) ? 0.f : cand;
+            const float delta = bcast(delta_j, e);
+            res = fmaf(acol, delta, res);
+            const float md = lane == e ? delta_j : 0.f;
+            fj += md;
+            imp = fmaf(md, t, imp);
+            acol = acol1; acol1 = acol2;
+          }
+          const float improvement = -wave_sum_fast(imp);
+          if (improvement * M.pgs_scale < M.solver_tolerance) break;
+        }
+        if (isr) EP[je * 8 + 4] = fj;
+        WSYNC();
+        if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], bcast(fj, e), w); w *= dinv_m; }
+      } else {
+        // (7) diagA, w0 = D^-1 Y' f, dual cost of the warm start; zero it if it is worse than f = 0
         for (int e = lane; e < nefc; e += 64) {
-          const float* y = YJ + e * nvs; const float* ep = EP + e * 8; float af = ep[2] * ep[4];
-          for (int d = 0; d < nv; d++) af = fmaf(y[d], WW[d], af);
-          cost += ep[4] * (0.5f * af + ep[3]);
+          const float* y = YJ + e * nvs; float s = 0.f;
+          for (int d = 0; d < nv; d++) s = fmaf(y[d] * y[d], DI[d], s);
+          const float da = s + EP[e * 8 + 2];
+          EP[e * 8 + 5] = da; EP[e * 8] = 1.0f / da;                   // pos is no longer needed: slot 0 = 1/A_ee
         }
-        cost = wave_sum_fast(cost);
-        if (cost > 0.f) { w = 0.f; for (int e = lane; e < nefc; e += 64) EP[e * 8 + 4] = 0.f; }
-      }
-      WSYNC();
-      // (8) PGS (mj_solPGS): rows in order, f_e <- max(0, f_e - res/A_ee), revert a row if its cost change > 1e-10
-      for (int itp = 0; itp < M.solver_iterations; itp++) {
-        float improvement = 0.f;
-        for (int e = 0; e < nefc; e++) {
-          const float4 e0 = *(const float4*)(EP + e * 8);          // 1/A_ee, aref, R, b
-          const float2 e1 = *(const float2*)(EP + e * 8 + 4);      // force, diagA
-          const float y = isd ? YJ[e * nvs + lane] : 0.f;
-          const float res = e0.w + wave_sum_fast(y * w) + e0.z * e1.x;
-          float fnew = fmaxf(0.f, e1.x - res * e0.x);
-          float delta = fnew - e1.x;
-          float change = 0.5f * delta * delta * e1.y + delta * res;
-          if (change > 1e-10f) { fnew = e1.x; delta = 0.f; change = 0.f; }
-          improvement -= change;
-          w = fmaf(delta * dinv_m, y, w);
-          if (lane == 0) EP[e * 8 + 4] = fnew;
+        if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], EP[e * 8 + 4], w); w *= dinv_m; WW[lane] = w; }
+        WSYNC();
+        {
+          float cost = 0.f;
+          for (int e = lane; e < nefc; e += 64) {
+            const float* y = YJ + e * nvs; const float* ep = EP + e * 8; float af = ep[2] * ep[4];
+            for (int d = 0; d < nv; d++) af = fmaf(y[d], WW[d], af);
+            cost += ep[4] * (0.5f * af + ep[3]);
+          }
+          cost = wave_sum_fast(cost);
+          if (cost > 0.f) { w = 0.f; for (int e = lane; e < nefc; e += 64) EP[e * 8 + 4] = 0.f; }
         }
-        if (improvement * M.pgs_scale < M.solver_tolerance) break;
+        WSYNC();
+        // (8) PGS (mj_solPGS): rows in order, f_e <- max(0, f_e - res/A_ee), revert a row if its cost change > 1e-10
+        for (int itp = 0; itp < M.solver_iterations; itp++) {
+          float improvement = 0.f;
+          for (int e = 0; e < nefc; e++) {
+            const float4 e0 = *(const float4*)(EP + e * 8);          // 1/A_ee, aref, R, b
+            const float2 e1 = *(const float2*)(EP + e * 8 + 4);      // force, diagA
+            const float y = isd ? YJ[e * nvs + lane] : 0.f;
+            const float res = e0.w + wave_sum_fast(y * w) + e0.z * e1.x;
+            float fnew = fmaxf(0.f, e1.x - res * e0.x);
+            float delta = fnew - e1.x;
+            float change = 0.5f * delta * delta * e1.y + delta * res;
+            if (change > 1e-10f) { fnew = e1.x; delta = 0.f; change = 0.f; }
+            improvement -= change;
+            w = fmaf(delta * dinv_m, y, w);
+            if (lane == 0) EP[e * 8 + 4] = fnew;
+          }
+          if (improvement * M.pgs_scale < M.solver_tolerance) break;
+        }
+        WSYNC();
       }
-      WSYNC();
+      STAMP(19);  // PGS
       // (9) qfrc_constraint = J' f = L'(Y' f) ; qacc = qacc_smooth + L^-1 w  (saved as next step's warm start)
       {
         const float u = isd ? w / dinv_m : 0.f;                      // (Y' f)_d
@@ -1291,6 +1395,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         }
         if (isd) { const float qa = xs + xa; QW[lane] = qa; if (!(fabsf(qa) <= 1e10f)) warn |= FMJ_WARN_BADQACC; }
       }
+      STAMP(20);  // qfrc_constraint + warm start
       // (10) sensors: joint limit force; contact forces in the contact frame (mj_contactForce, pyramidal)
       {
         float lf = 0.f;

@@ -4,11 +4,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from farms_mujoco_amd import _lib
 _lib.SO_PATH = os.path.join(_lib.CSRC, 'libfmj_hip_stamps.so')
 import torch, bench
-names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L', 'X', 'Euler']
+names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L', 'X', 'Euler', 'facM', 'collide', 'Jrows', 'rowprm', 'Y',
+         'A', 'warm', 'PGS', 'qfrc_c', '-', '-', '-']
+workload = os.environ.get('FMJ_WORKLOAD', 'swim')
 for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
-    sim, m, _ = bench.build_sim(n, 300, 100, 0, 'cuda:0')
+    sim, m, _ = bench.build_sim(n, 300, 100, 0, 'cuda:0', workload)
     sim.step_fused(100); sim.step_fused(100); torch.cuda.synchronize()
-    st = sim.physics.data.qacc[0, :12].cpu().numpy()/100.0
+    st = sim.physics.data.qacc[0, :24].cpu().numpy()/100.0
     tot = st.sum()
     print(f'n_envs={n}: cycles/step {tot:.0f}')
     print('  ' + '  '.join(f'{k}:{v:.0f}({100*v/tot:.0f}%)' for k, v in zip(names, st)))
+    if workload == 'walk':
+        nc = sim.physics.data.ncon.float()
+        print(f'  ncon mean {nc.mean().item():.1f} max {nc.max().item():.0f} env0 {nc[0].item():.0f}')
