@@ -61,6 +61,7 @@ struct DevModel {
   const float4* gtab;         // [ngeom][GT_STRIDE]
   const float4* ptab;         // [nplane][PT_STRIDE]
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
+  const int8_t* lcad;         // [nv][nv] depth of the deepest dof the chains of two dofs share (-1: none), padded to 4 bytes
   // ---- constraint path (joint limits, plane contacts, pyramidal cone, PGS) ----
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
@@ -326,7 +327,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
   int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
-  int HM, YJ, EP, CT, XS, WW, QW, DI, PO, AT, na;      // constraint path only
+  int HM, YJ, EP, CT, XS, WW, QW, DI, PO, AT, LC, na;      // constraint path only
 };
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
                                                 int maxcon = 0, int nvs = 0) {
@@ -345,10 +346,10 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.VT = o; o += 8;
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
-  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = L.AT = o; L.na = 0;
+  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = L.AT = L.LC = o; L.na = 0;
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
-    L.YJ = o; o += r4(maxefc * nvs);  // constraint Jacobian rows J, then Y = J L^-1
+    L.YJ = o; o += r4(maxefc * rs);   // compact constraint Jacobian rows J (rs entries along the row's dof chain), then Y = J L^-1
     L.EP = o; o += maxefc * 8;        // per row: pos, margin/aref, R, b, force, diagA, type|id, mu
     L.CT = o; o += maxcon * 16;       // contacts: pos(3) normal(3) t1(3) t2(3) dist mu geom plane
     L.XS = o; o += r4(nv);            // qacc_smooth
@@ -358,6 +359,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
     L.na = maxefc < 64 ? maxefc : 64; // rows the explicit PGS matrix holds (one row per lane)
     L.AT = o; o += r4(L.na * (L.na + 1) / 2);   // packed lower triangle of A + diag(R)
+    L.LC = o; o += r4((nv * nv + 3) / 4);        // int8 [nv][nv]: depth of the deepest dof two chains share (-1: none)
   }
   o = r4(o);
   L.total = o;
@@ -646,7 +648,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
   float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
   float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EP = lds + LL.EP;  float* CT = lds + LL.CT;
   float* XS = lds + LL.XS;  float* WW = lds + LL.WW;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
-  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;
+  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;  float* LC = lds + LL.LC;
   const int nvs = M.nvs;
 
   const bool isb = lane > 0 && lane < nb;
@@ -672,6 +674,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
     for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
     if (lane < 8) VT[lane] = 0.f;
     if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
+    if (CONS) for (int i = lane; i < (nv * nv + 3) / 4; i += 64) ((uint32_t*)LC)[i] = ((const uint32_t*)M.lcad)[i];
   }
   int cy_ncon = 0;                                  // contacts of the last forward pass (records incl. forces stay in CT)
   if (CONS && FUSED && A.contacts_rows) {
@@ -1156,12 +1159,14 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       const int nefc = nlim + 4 * ncon;
       WSYNC();
       STAMP(13);  // limits + contacts
-      // (4) Jacobian rows.  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d =
-      //     cdof_lin + cdof_rot x (p - com) for the dofs on the body's chain.
-      for (int i = lane; i < nefc * nvs; i += 64) YJ[i] = 0.f;
+      // (4) Jacobian rows, stored compactly: a row touches only the dofs on the chain from its body to the root, so
+      //     YC[e][dd] is the entry at the chain's dof of depth dd (RS floats per row) and ep[6] names the chain's last
+      //     dof.  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
+      float* YC = YJ;
+      for (int i = lane; i < nefc * RS; i += 64) YC[i] = 0.f;
       WSYNC();
-      if (act_lo) { YJ[e_lo * nvs + lane] = 1.f;  float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
-      if (act_hi) { YJ[e_hi * nvs + lane] = -1.f; float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
+      if (act_lo) { YC[e_lo * RS + ddepth] = 1.f;  float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(((lane + 1) << 8) | lane); ep[7] = 0.f; }
+      if (act_hi) { YC[e_hi * RS + ddepth] = -1.f; float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(((lane + 1) << 8) | lane); ep[7] = 0.f; }
       {
         const s6 cd = isd ? lds_get6(CD + lane * 8) : s6{mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
         for (int c = 0; c < ncon; c++) {
@@ -1170,45 +1175,90 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           const int g = __float_as_int(c3.z);
           const int last = GTABI(g, 0).z;                       // last dof on the contact body's chain
           const bool on = isd && last >= 0 && lane <= last && last < lane + dsub;
-          const v3 jp = add3(cd.l, cross(cd.r, sub3(mk3(c0.x, c0.y, c0.z), com)));
-          const float jn = on ? dot3(jp, mk3(c0.w, c1.x, c1.y)) : 0.f;
-          const float j1 = on ? c3.y * dot3(jp, mk3(c1.z, c1.w, c2.x)) : 0.f;
-          const float j2 = on ? c3.y * dot3(jp, mk3(c2.y, c2.z, c2.w)) : 0.f;
-          if (isd) {
-            float* y = YJ + (nlim + 4 * c) * nvs + lane;
-            y[0] = jn + j1; y[nvs] = jn - j1; y[2 * nvs] = jn + j2; y[3 * nvs] = jn - j2;
+          if (on) {
+            const v3 jp = add3(cd.l, cross(cd.r, sub3(mk3(c0.x, c0.y, c0.z), com)));
+            const float jn = dot3(jp, mk3(c0.w, c1.x, c1.y));
+            const float j1 = c3.y * dot3(jp, mk3(c1.z, c1.w, c2.x));
+            const float j2 = c3.y * dot3(jp, mk3(c2.y, c2.z, c2.w));
+            float* y = YC + (nlim + 4 * c) * RS + ddepth;
+            y[0] = jn + j1; y[RS] = jn - j1; y[2 * RS] = jn + j2; y[3 * RS] = jn - j2;
           }
-          if (lane < 4) { float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | c); ep[7] = c3.y; }
+          if (lane < 4) { float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | ((last + 1) << 8) | c); ep[7] = c3.y; }
         }
       }
       WSYNC();
       STAMP(14);  // J rows
-      // (5) per row (lane = row): R, aref (mj_makeImpedance / mj_referenceConstraint), b = J qacc_smooth - aref,
-      //     warm-start force from the previous qacc (mj_fwdConstraint)
-      for (int e = lane; e < nefc; e += 64) {
-        float* ep = EP + e * 8;
+      // (5) per row (lane = row, 64 rows per pass): R, aref (mj_makeImpedance / mj_referenceConstraint),
+      //     b = J qacc_smooth - aref, warm-start jar from the previous qacc (mj_fwdConstraint), then
+      // (6) Y = J L^-1 with the row in registers: walking the chain from its last dof i to the root,
+      //     y[dd2] -= L[i][dd2] y[depth(i)] for dd2 < depth(i).  yh = Y D^-1 stays in registers for (7a).
+      float yh[MAXD];
+      int chain = -1;
+      for (int e0 = 0; e0 < nefc; e0 += 64) {
+        const int e = e0 + lane;
+        const bool isr = e < nefc;
+        float* ep = EP + (isr ? e : 0) * 8;
         const int tid = __float_as_int(ep[6]);
         const bool is_con = (tid & 0x40000000) != 0;
+        chain = isr ? ((tid >> 8) & 0xff) - 1 : -1;
         float sr0, sr1, si0, si1, si2, si3, si4, dapx;
         const float mu = ep[7];
         if (is_con) {
-          const float4 c3 = *(const float4*)(CT + (tid & 0xffff) * 16 + 12);
+          const float4 c3 = *(const float4*)(CT + (tid & 0xff) * 16 + 12);
           const int g = __float_as_int(c3.z);
           const float4 a = GTAB(g, 4), b = GTAB(g, 5);
           sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z;
           const float tran = GTAB(g, 2).w;                       // invweight0 of the body (+ 0 for the world plane)
           dapx = tran + mu * mu * tran;
         } else {
-          const float4 a = DTAB(tid, 4), b = DTAB(tid, 5);
+          const float4 a = DTAB(tid & 0xff, 4), b = DTAB(tid & 0xff, 5);
           sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z; dapx = b.w;
         }
         float R, kimp, bb;
         row_params(sr0, sr1, si0, si1, si2, si3, si4, ep[0], ep[1], dapx, h, &R, &kimp, &bb);
+        float y[MAXD];
+        {
+          const float* yr = YC + (isr ? e : 0) * RS;
+#pragma unroll
+          for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); y[4 * g4] = v.x; y[4 * g4 + 1] = v.y; y[4 * g4 + 2] = v.z; y[4 * g4 + 3] = v.w; }
+        }
+        const int cdep_raw = __builtin_amdgcn_ds_bpermute((chain < 0 ? 0 : chain) << 2, ddepth);   // all lanes take part: a masked-off source lane reads as 0
+        const int cdep = chain >= 0 ? cdep_raw : -1;
+        int ii[MAXD];                                             // the chain's dof at each depth (0 beyond the chain)
         float vel = 0.f, jxs = 0.f, jqw = 0.f;
-        const float* y = YJ + e * nvs;
-        for (int d = 0; d < nv; d++) { const float j = y[d]; vel = fmaf(j, QV[d], vel); jxs = fmaf(j, XS[d], jxs); jqw = fmaf(j, QW[d], jqw); }
+        {
+          int i = chain < 0 ? 0 : chain;
+#pragma unroll
+          for (int dd = MAXD - 1; dd >= 0; dd--) {
+            if (dd < MAXD - 1) { const int pi = __builtin_amdgcn_ds_bpermute(i << 2, dparent); i = dd < cdep ? pi : i; }
+            ii[dd] = dd <= cdep ? i : 0;
+            const float j = y[dd];
+            vel = fmaf(j, QV[ii[dd]], vel); jxs = fmaf(j, XS[ii[dd]], jxs); jqw = fmaf(j, QW[ii[dd]], jqw);
+          }
+        }
         const float aref = -bb * vel - kimp * (ep[0] - ep[1]);
-        ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
+#pragma unroll
+        for (int dd = MAXD - 1; dd >= 1; dd--) {
+          const float yi = y[dd];
+          const float* lr = HM + ii[dd] * RS;
+#pragma unroll
+          for (int g4 = 0; g4 < (dd + 3) / 4; g4++) {
+            const float4 l4 = *(const float4*)(lr + 4 * g4);
+            if (4 * g4 + 0 < dd) y[4 * g4 + 0] = fmaf(-l4.x, yi, y[4 * g4 + 0]);
+            if (4 * g4 + 1 < dd) y[4 * g4 + 1] = fmaf(-l4.y, yi, y[4 * g4 + 1]);
+            if (4 * g4 + 2 < dd) y[4 * g4 + 2] = fmaf(-l4.z, yi, y[4 * g4 + 2]);
+            if (4 * g4 + 3 < dd) y[4 * g4 + 3] = fmaf(-l4.w, yi, y[4 * g4 + 3]);
+          }
+        }
+        float ayy = 0.f;                                          // A_ee without R
+#pragma unroll
+        for (int dd = 0; dd < MAXD; dd++) { yh[dd] = y[dd] * DI[ii[dd]]; ayy = fmaf(yh[dd], y[dd], ayy); }
+        if (isr) {
+          float* yr = YC + e * RS;
+#pragma unroll
+          for (int g4 = 0; g4 < MAXD / 4; g4++) *(float4*)(yr + 4 * g4) = make_float4(y[4 * g4], y[4 * g4 + 1], y[4 * g4 + 2], y[4 * g4 + 3]);
+          ep[0] = ayy; ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
+        }
       }
       WSYNC();
       // pyramidal: the 4 rows of a contact share R = 2 mu^2 R_first (mu scaled by 1/sqrt(impratio))
@@ -1216,75 +1266,45 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         float* ep = EP + e * 8;
         const int tid = __float_as_int(ep[6]);
         if (tid & 0x40000000) {
-          const int e0 = nlim + 4 * (tid & 0xffff);
+          const int e0 = nlim + 4 * (tid & 0xff);
           const float mu = ep[7] * M.impratio_isqrt;
           ep[2] = fmaxf(1e-15f, 2.f * mu * mu * EP[e0 * 8 + 5]);
         }
       }
       WSYNC();
       for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f; }
-      STAMP(15);  // row params
-      // (6) Y = J L^-1 (lane = row): y_a -= L[i][a] y_i for every dof i (leaves first) and ancestor a.
-      //     The ancestors of i are walked once (uniform), then the row's loads, FMAs and stores go out in batches.
-      for (int i = nv - 1; i >= 1; i--) {
-        const int depi = __builtin_amdgcn_readlane(ddepth, i);
-        if (depi == 0) continue;
-        {   // nothing to do when no row has weight on dof i (rows beyond the first 64 are checked per batch below)
-          bool nz = false;
-          for (int e = lane; e < nefc; e += 64) nz |= YJ[e * nvs + i] != 0.f;
-          if (!__any(nz)) continue;
-        }
-        int anc[MAXD];
-        { int a = i;
-#pragma unroll
-          for (int dd = MAXD - 1; dd >= 0; dd--) { if (dd < depi) a = __builtin_amdgcn_readlane(dparent, a); anc[dd] = a; } }
-        for (int e0 = 0; e0 < nefc; e0 += 64) {
-          const int e = e0 + lane;
-          float* y = YJ + (e < nefc ? e : 0) * nvs;
-          const float yi = e < nefc ? y[i] : 0.f;
-          if (!__any(yi != 0.f)) continue;
-          float yv[MAXD];
-#pragma unroll
-          for (int dd = 0; dd < MAXD; dd++) yv[dd] = y[anc[dd]];
-#pragma unroll
-          for (int g = 0; g < MAXD / 4; g++) {
-            const float4 l4 = *(const float4*)(HM + i * RS + 4 * g);
-            yv[4 * g + 0] = fmaf(4 * g + 0 < depi ? -l4.x : 0.f, yi, yv[4 * g + 0]);
-            yv[4 * g + 1] = fmaf(4 * g + 1 < depi ? -l4.y : 0.f, yi, yv[4 * g + 1]);
-            yv[4 * g + 2] = fmaf(4 * g + 2 < depi ? -l4.z : 0.f, yi, yv[4 * g + 2]);
-            yv[4 * g + 3] = fmaf(4 * g + 3 < depi ? -l4.w : 0.f, yi, yv[4 * g + 3]);
-          }
-          if (e < nefc) {
-#pragma unroll
-            for (int dd = 0; dd < MAXD; dd++) if (dd < depi) y[anc[dd]] = yv[dd];
-          }
-        }
-      }
       WSYNC();
-      STAMP(16);  // Y
+      STAMP(16);  // row params + Y
       float w = 0.f;
       if (nefc <= LL.na) {
-        // (7a) explicit A = Y D^-1 Y' + diag(R), packed lower triangle in LDS, lane = row; 4 columns per pass
+        // (7a) explicit A = Y D^-1 Y' + diag(R), packed lower triangle in LDS, lane = row.  Rows e and f share the dofs
+        //      of depth <= lcad(chain_e, chain_f); yh is masked once per run of columns with the same chain.
         const bool isr = lane < nefc;
         const int je = isr ? lane : 0;
         const int tri = je * (je + 1) / 2;
         {
-          const float* ye = YJ + je * nvs;
-          for (int f0 = 0; f0 < nefc; f0 += 4) {
-            const int r1 = f0 + 1 < nefc ? f0 + 1 : f0, r2 = f0 + 2 < nefc ? f0 + 2 : f0, r3 = f0 + 3 < nefc ? f0 + 3 : f0;
-            const float* y0 = YJ + f0 * nvs; const float* y1 = YJ + r1 * nvs; const float* y2 = YJ + r2 * nvs; const float* y3 = YJ + r3 * nvs;
-            float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-            for (int d = 0; d < nv; d++) {
-              const float t = ye[d] * DI[d];
-              a0 = fmaf(t, y0[d], a0); a1 = fmaf(t, y1[d], a1); a2 = fmaf(t, y2[d], a2); a3 = fmaf(t, y3[d], a3);
+          const int8_t* LCB = (const int8_t*)LC;
+          const float Rj = EP[je * 8 + 2];
+          float ym[MAXD];
+#pragma unroll
+          for (int dd = 0; dd < MAXD; dd++) ym[dd] = 0.f;
+          int cprev = -2;
+          for (int f = 0; f < nefc; f++) {
+            const int cf = __builtin_amdgcn_readlane(chain, f);
+            if (cf != cprev) {
+              cprev = cf;
+              const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
+#pragma unroll
+              for (int dd = 0; dd < MAXD; dd++) ym[dd] = dd <= l ? yh[dd] : 0.f;
             }
-            if (isr) {
-              const float Rj = EP[je * 8 + 2];
-              if (f0 <= je)                   AT[tri + f0]     = a0 + (f0 == je ? Rj : 0.f);
-              if (f0 + 1 <= je)               AT[tri + f0 + 1] = a1 + (f0 + 1 == je ? Rj : 0.f);
-              if (f0 + 2 <= je)               AT[tri + f0 + 2] = a2 + (f0 + 2 == je ? Rj : 0.f);
-              if (f0 + 3 <= je)               AT[tri + f0 + 3] = a3 + (f0 + 3 == je ? Rj : 0.f);
+            const float* yf = YC + f * RS;
+            float a0 = 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < MAXD / 4; g4++) {
+              const float4 v = *(const float4*)(yf + 4 * g4);
+              a0 = fmaf(ym[4 * g4], v.x, a0); a0 = fmaf(ym[4 * g4 + 1], v.y, a0); a0 = fmaf(ym[4 * g4 + 2], v.z, a0); a0 = fmaf(ym[4 * g4 + 3], v.w, a0);
             }
+            if (isr && f <= je) AT[tri + f] = a0 + (f == je ? Rj : 0.f);
           }
         }
         WSYNC();
@@ -1311,6 +1331,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         //      Column e of the packed triangle for row j sits at max(tri(j) + e, tri(e) + j); fetched two rows ahead.
         const float hdiag = 0.5f * diag;
         const float nainv = -ainv;
+        float nf = -fj;
         for (int itp = 0; itp < M.solver_iterations; itp++) {
           float imp = 0.f;
           float acol = AT[tri], acol1 = AT[nefc > 1 ? max(tri + 1, 1 + je) : tri];
@@ -1318,39 +1339,46 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           for (int e = 0; e < nefc; e++) {
             tcol += e + 2;                                            // tri(e + 2)
             const float acol2 = AT[e + 2 < nefc ? max(tri + e + 2, tcol + je) : tri];
-            const float cand = fmaxf(-fj, res * nainv);
+            const float cand = fmaxf(nf, res * nainv);
             const float t = fmaf(hdiag, cand, res);
             const float delta_j = (cand * t > 1e-10f) ? 0.f : cand;
             const float delta = bcast(delta_j, e);
             res = fmaf(acol, delta, res);
             const float md = lane == e ? delta_j : 0.f;
-            fj += md;
+            nf -= md;
             imp = fmaf(md, t, imp);
             acol = acol1; acol1 = acol2;
           }
           const float improvement = -wave_sum_fast(imp);
           if (improvement * M.pgs_scale < M.solver_tolerance) break;
         }
+        fj = -nf;
         if (isr) EP[je * 8 + 4] = fj;
-        WSYNC();
-        if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], bcast(fj, e), w); w *= dinv_m; }
-      } else {
-        // (7) diagA, w0 = D^-1 Y' f, dual cost of the warm start; zero it if it is worse than f = 0
-        for (int e = lane; e < nefc; e += 64) {
-          const float* y = YJ + e * nvs; float s = 0.f;
-          for (int d = 0; d < nv; d++) s = fmaf(y[d] * y[d], DI[d], s);
-          const float da = s + EP[e * 8 + 2];
-          EP[e * 8 + 5] = da; EP[e * 8] = 1.0f / da;                   // pos is no longer needed: slot 0 = 1/A_ee
-        }
-        if (isd) { for (int e = 0; e < nefc; e++) w = fmaf(YJ[e * nvs + lane], EP[e * 8 + 4], w); w *= dinv_m; WW[lane] = w; }
-        WSYNC();
-        {
-          float cost = 0.f;
-          for (int e = lane; e < nefc; e += 64) {
-            const float* y = YJ + e * nvs; const float* ep = EP + e * 8; float af = ep[2] * ep[4];
-            for (int d = 0; d < nv; d++) af = fmaf(y[d], WW[d], af);
-            cost += ep[4] * (0.5f * af + ep[3]);
+        if (isd) {
+          for (int e = 0; e < nefc; e++) {
+            const int ce = __builtin_amdgcn_readlane(chain, e);
+            const bool on = lane <= ce && ce < lane + dsub;
+            w = fmaf(on ? YC[e * RS + ddepth] : 0.f, bcast(fj, e), w);
           }
+          w *= dinv_m;
+        }
+        WSYNC();
+      } else {
+        // (7) more rows than lanes: matrix-free PGS.  A = Y D^-1 Y' is never formed; lanes hold w = D^-1 Y' f per dof
+        //     and a row residual is b_e + y_e.w + R_e f_e (one wave reduction per row).
+        for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float da = ep[0] + ep[2]; ep[5] = da; ep[0] = 1.0f / da; }
+        WSYNC();
+        if (isd) {
+          for (int e = 0; e < nefc; e++) {
+            const int ce = ((__float_as_int(EP[e * 8 + 6]) >> 8) & 0xff) - 1;
+            const bool on = lane <= ce && ce < lane + dsub;
+            w = fmaf(on ? YC[e * RS + ddepth] : 0.f, EP[e * 8 + 4], w);
+          }
+          w *= dinv_m;
+        }
+        {   // dual cost of the warm start: sum_e f (0.5 R f + b) + 0.5 w' D w ; zero the start if f = 0 is better
+          float cost = isd ? 0.5f * w * w / dinv_m : 0.f;
+          for (int e = lane; e < nefc; e += 64) { const float* ep = EP + e * 8; cost += ep[4] * (0.5f * ep[2] * ep[4] + ep[3]); }
           cost = wave_sum_fast(cost);
           if (cost > 0.f) { w = 0.f; for (int e = lane; e < nefc; e += 64) EP[e * 8 + 4] = 0.f; }
         }
@@ -1360,8 +1388,9 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           float improvement = 0.f;
           for (int e = 0; e < nefc; e++) {
             const float4 e0 = *(const float4*)(EP + e * 8);          // 1/A_ee, aref, R, b
-            const float2 e1 = *(const float2*)(EP + e * 8 + 4);      // force, diagA
-            const float y = isd ? YJ[e * nvs + lane] : 0.f;
+            const float4 e1 = *(const float4*)(EP + e * 8 + 4);      // force, diagA, type|chain|id, mu
+            const int ce = ((__float_as_int(e1.z) >> 8) & 0xff) - 1;
+            const float y = (isd && lane <= ce && ce < lane + dsub) ? YC[e * RS + ddepth] : 0.f;
             const float res = e0.w + wave_sum_fast(y * w) + e0.z * e1.x;
             float fnew = fmaxf(0.f, e1.x - res * e0.x);
             float delta = fnew - e1.x;
@@ -1834,6 +1863,16 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->h_d_info.assign((int*)d_info.data(), (int*)d_info.data() + 64 * 4);
 
   UP(b_anc, b_anc);
+  {   // depth of the deepest dof shared by the root chains of two dofs (constraint rows couple only through it)
+    std::vector<int8_t> lcad((size_t)r4(nv * nv), (int8_t)-1);
+    for (int a = 0; a < nv; a++)
+      for (int b = 0; b < nv; b++) {
+        int x = a, y = b;
+        while (x >= 0 && y >= 0 && x != y) { if (ddepth[x] > ddepth[y]) x = m->dof_parentid[x]; else if (ddepth[y] > ddepth[x]) y = m->dof_parentid[y]; else { x = m->dof_parentid[x]; y = m->dof_parentid[y]; } }
+        lcad[(size_t)a * nv + b] = (x >= 0 && x == y) ? (int8_t)ddepth[x] : (int8_t)-1;
+      }
+    UP(lcad, lcad);
+  }
   // ---- constraint tables
   D.cons = cons; D.ngeom = m->ngeom; D.nplane = nplane; D.nvs = nv | 1;
   D.max_contacts = cons ? (m->max_contacts > 0 ? m->max_contacts : 1) : 0;
