@@ -73,6 +73,37 @@ def test_single_step_with_contacts_and_limit(oracle):
         assert np.allclose(got[:, 3:6], [0, 0, 1], atol=1e-7)
 
 
+def test_many_contacts_more_rows_than_lanes(oracle):
+    """Belly on the ground: 24+ contacts = 96+ pyramid rows, more than the 64 rows the explicit PGS matrix holds, so
+    the matrix-free PGS path runs; envs with few contacts in the same batch take the explicit path."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _walker(spawn_z=0.01)
+    n = 8
+    rng = np.random.default_rng(3)
+    qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.05, 0.05, (n, m.nq - 7))
+    qpos[n//2:, 2] = 0.045                         # second half stands on its feet
+    qvel = rng.normal(size=(n, m.nv))*0.02
+    phys = BatchedPhysics(m, n)
+    q32, v32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref)
+    assert max(fd['nefc'] for fd in fds) > 64 and min(fd['nefc'] for fd in fds) <= 64
+    for k, tol in (('xpos', 2e-6), ('qvel', 2e-3), ('qpos', 1e-5)):
+        assert _relerr(getattr(d, k).cpu().numpy(), ref[k]) < tol, (k, _relerr(getattr(d, k).cpu().numpy(), ref[k]))
+    for e in (0, n - 1):
+        fd = fds[e]
+        f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4)
+        got = d.contact.cpu().numpy()[e, :fd['ncon']]
+        assert np.allclose(got[:, 12], f.sum(1), rtol=2e-2, atol=2e-4), np.abs(got[:, 12] - f.sum(1)).max()
+
+
 def test_joint_limit_holds(oracle):
     """Position actuator drives a spine joint to 1.5 rad; the +1.2 rad limit stops it and jointlimitfrc reports the
     constraint force (row and sensordata), matching the oracle."""
