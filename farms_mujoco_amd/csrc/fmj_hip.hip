@@ -61,6 +61,8 @@ struct DevModel {
   const float4* gtab;         // [ngeom][GT_STRIDE]
   const float4* ptab;         // [nplane][PT_STRIDE]
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
+  float* cons_rows;           // [n_envs][maxefc][8] row parameters of envs with more rows than LDS holds
+  float* cons_a;              // [n_envs][maxefc][AG_LD] their PGS matrix
   const int8_t* lcad;         // [nv][nv] depth of the deepest dof the chains of two dofs share (-1: none), padded to 4 bytes
   // ---- constraint path (joint limits, plane contacts, pyramidal cone, PGS) ----
   int cons;                   // 1 if the model has limits or collision geoms
@@ -327,18 +329,15 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
   int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
-  int HM, YJ, EP, CT, XS, WW, QW, DI, PO, AT, LC, na;      // constraint path only
+  int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
 };
+#define AG_LD 192      // row length of the global PGS matrix (three 64-lane slots)
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
                                                 int maxcon = 0, int nvs = 0) {
   LdsLayout L;
   const int nmax = nb > nv ? nb : nv;
   int o = 0;
   // every region starts on a 16-byte boundary (float4 LDS accesses; a misaligned ds_read_b128 is split and stalls)
-  L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
-  L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
-  L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
-  L.CD = o; o += nv * 8;              // cdof
   L.HR = o; o += nv * rs;             // depth-indexed rows of H = M + h B, then its L'DL
   L.QP = o; o += r4(nq);
   L.QV = o; o += r4(nv);
@@ -346,21 +345,37 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.VT = o; o += 8;
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
-  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.PO = L.AT = L.LC = o; L.na = 0;
+  L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.SD = L.PO = L.AT = L.LC = L.CH = o; L.na = 0;
+  const int dead = 2 * nmax * 8 + r4(nb * 12);   // T/F, V/BUF, CI: not live between the M phase and the next step
+  int atx = 0;
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
-    L.YJ = o; o += r4(maxefc * rs);   // compact constraint Jacobian rows J (rs entries along the row's dof chain), then Y = J L^-1
-    L.EP = o; o += maxefc * 8;        // per row: pos, margin/aref, R, b, force, diagA, type|id, mu
     L.CT = o; o += maxcon * 16;       // contacts: pos(3) normal(3) t1(3) t2(3) dist mu geom plane
     L.XS = o; o += r4(nv);            // qacc_smooth
-    L.WW = o; o += r4(nv);            // w = D^-1 Y' f
+    L.WW = o; o += r4(nv);            // (spare)
     L.QW = o; o += r4(nv);            // qacc_warmstart
     L.DI = o; o += r4(nv);            // 1/D of the M factor
+    L.SD = o; o += r4(nv);            // 1/sqrt(D)
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
-    L.na = maxefc < 64 ? maxefc : 64; // rows the explicit PGS matrix holds (one row per lane)
-    L.AT = o; o += r4(L.na * (L.na + 1) / 2);   // packed lower triangle of A + diag(R)
     L.LC = o; o += r4((nv * nv + 3) / 4);        // int8 [nv][nv]: depth of the deepest dof two chains share (-1: none)
+    L.CH = o; o += r4((maxefc + 3) / 4);         // uint8 per row: last dof of the row's chain + 1
+    // Rows.  Up to na rows ("small") everything is in LDS: YJ = na compact rows, EP = their parameters, AT = packed
+    // triangle of A, which also covers T/F, V/BUF, CI and cdof (dead once the Jacobian rows exist).  With more rows
+    // the row vectors alone take YJ..CI (cdof is still read while they are written), parameters and A live in HBM.
+    L.na = maxefc < 60 ? maxefc : 60;
+    L.YJ = o; o += L.na * rs;
+    L.EP = o; o += L.na * 8;
+    const int tri = r4(L.na * (L.na + 1) / 2);
+    atx = tri - (dead + nv * 8); if (atx < 0) atx = 0;
+    const int big = r4(maxefc * rs) - (L.na * rs + L.na * 8 + dead);      // floats the spilled rows need beyond YJ, EP, dead
+    if (atx < big) atx = big;
+    atx = r4(atx);
+    L.AT = o; o += atx;
   }
+  L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
+  L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
+  L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
+  L.CD = o; o += nv * 8;              // cdof
   o = r4(o);
   L.total = o;
   return L;
@@ -628,7 +643,7 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 #endif
 
 template <bool FUSED, int MAXD, bool CONS>
-__global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
+__global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = blockIdx.x;
   const int lane = threadIdx.x;
@@ -646,9 +661,9 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
   float* VT = lds + LL.VT;
   const uint8_t* JMP = (const uint8_t*)(lds + LL.ANC);   // [nb][anc_stride]: ancestor at distance 2^r
   float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
-  float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EP = lds + LL.EP;  float* CT = lds + LL.CT;
+  float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EPL = lds + LL.EP;  float* CT = lds + LL.CT;
   float* XS = lds + LL.XS;  float* WW = lds + LL.WW;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
-  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;  float* LC = lds + LL.LC;
+  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;  float* LC = lds + LL.LC;  float* SD = lds + LL.SD;  float* CH = lds + LL.CH;
   const int nvs = M.nvs;
 
   const bool isb = lane > 0 && lane < nb;
@@ -1093,7 +1108,7 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         ldl_factor<MAXD>(HM, lane, isd, ddepth, dsub, nv, dinv_m);
       }
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
-      if (isd) { XS[lane] = xs; DI[lane] = dinv_m; }
+      if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); }
       STAMP(12);  // factor M + qacc_smooth
       // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
       const float4 lim = DTAB(dlo, 3);
@@ -1160,13 +1175,19 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
       WSYNC();
       STAMP(13);  // limits + contacts
       // (4) Jacobian rows, stored compactly: a row touches only the dofs on the chain from its body to the root, so
-      //     YC[e][dd] is the entry at the chain's dof of depth dd (RS floats per row) and ep[6] names the chain's last
-      //     dof.  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
+      //     YC[e][dd] is the entry at the chain's dof of depth dd (RS floats per row) and CHN[e] names the chain's last
+      //     dof (+1).  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
+      //     Up to LL.na rows everything stays in LDS ("small"); with more rows the row vectors spill over the regions
+      //     that are dead here (EP, AT, T/F, V/BUF, CI), the per-row parameters go to a global scratch and so does A.
+      const bool small = nefc <= LL.na;
       float* YC = YJ;
+      float* EP = small ? EPL : M.cons_rows + (size_t)env * M.maxefc * 8;
+      uint8_t* CHN = (uint8_t*)CH;
+#define RSYNC() do { if (!small) __threadfence(); WSYNC(); } while (0)
       for (int i = lane; i < nefc * RS; i += 64) YC[i] = 0.f;
       WSYNC();
-      if (act_lo) { YC[e_lo * RS + ddepth] = 1.f;  float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(((lane + 1) << 8) | lane); ep[7] = 0.f; }
-      if (act_hi) { YC[e_hi * RS + ddepth] = -1.f; float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(((lane + 1) << 8) | lane); ep[7] = 0.f; }
+      if (act_lo) { YC[e_lo * RS + ddepth] = 1.f;  CHN[e_lo] = (uint8_t)(lane + 1); float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
+      if (act_hi) { YC[e_hi * RS + ddepth] = -1.f; CHN[e_hi] = (uint8_t)(lane + 1); float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
       {
         const s6 cd = isd ? lds_get6(CD + lane * 8) : s6{mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
         for (int c = 0; c < ncon; c++) {
@@ -1183,24 +1204,22 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
             float* y = YC + (nlim + 4 * c) * RS + ddepth;
             y[0] = jn + j1; y[RS] = jn - j1; y[2 * RS] = jn + j2; y[3 * RS] = jn - j2;
           }
-          if (lane < 4) { float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | ((last + 1) << 8) | c); ep[7] = c3.y; }
+          if (lane < 4) { CHN[nlim + 4 * c + lane] = (uint8_t)(last + 1); float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | c); ep[7] = c3.y; }
         }
       }
-      WSYNC();
+      RSYNC();
       STAMP(14);  // J rows
       // (5) per row (lane = row, 64 rows per pass): R, aref (mj_makeImpedance / mj_referenceConstraint),
       //     b = J qacc_smooth - aref, warm-start jar from the previous qacc (mj_fwdConstraint), then
-      // (6) Y = J L^-1 with the row in registers: walking the chain from its last dof i to the root,
-      //     y[dd2] -= L[i][dd2] y[depth(i)] for dd2 < depth(i).  yh = Y D^-1 stays in registers for (7a).
-      float yh[MAXD];
-      int chain = -1;
+      // (6) Z = J L^-1 D^-1/2 with the row in registers: walking the chain from its last dof i to the root,
+      //     y[dd2] -= L[i][dd2] y[depth(i)] for dd2 < depth(i); A = J M^-1 J' = Z Z'.
       for (int e0 = 0; e0 < nefc; e0 += 64) {
         const int e = e0 + lane;
         const bool isr = e < nefc;
         float* ep = EP + (isr ? e : 0) * 8;
         const int tid = __float_as_int(ep[6]);
         const bool is_con = (tid & 0x40000000) != 0;
-        chain = isr ? ((tid >> 8) & 0xff) - 1 : -1;
+        const int chain = isr ? (int)CHN[e] - 1 : -1;
         float sr0, sr1, si0, si1, si2, si3, si4, dapx;
         const float mu = ep[7];
         if (is_con) {
@@ -1250,17 +1269,16 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
             if (4 * g4 + 3 < dd) y[4 * g4 + 3] = fmaf(-l4.w, yi, y[4 * g4 + 3]);
           }
         }
-        float ayy = 0.f;                                          // A_ee without R
 #pragma unroll
-        for (int dd = 0; dd < MAXD; dd++) { yh[dd] = y[dd] * DI[ii[dd]]; ayy = fmaf(yh[dd], y[dd], ayy); }
+        for (int dd = 0; dd < MAXD; dd++) y[dd] *= SD[ii[dd]];
         if (isr) {
           float* yr = YC + e * RS;
 #pragma unroll
           for (int g4 = 0; g4 < MAXD / 4; g4++) *(float4*)(yr + 4 * g4) = make_float4(y[4 * g4], y[4 * g4 + 1], y[4 * g4 + 2], y[4 * g4 + 3]);
-          ep[0] = ayy; ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
+          ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
         }
       }
-      WSYNC();
+      RSYNC();
       // pyramidal: the 4 rows of a contact share R = 2 mu^2 R_first (mu scaled by 1/sqrt(impratio))
       for (int e = lane; e < nefc; e += 64) {
         float* ep = EP + e * 8;
@@ -1270,39 +1288,45 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
           const float mu = ep[7] * M.impratio_isqrt;
           ep[2] = fmaxf(1e-15f, 2.f * mu * mu * EP[e0 * 8 + 5]);
         }
+        const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f;        // warm-start force
       }
-      WSYNC();
-      for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f; }
-      WSYNC();
-      STAMP(16);  // row params + Y
+      RSYNC();
+      STAMP(16);  // row params + Z
       float w = 0.f;
-      if (nefc <= LL.na) {
-        // (7a) explicit A = Y D^-1 Y' + diag(R), packed lower triangle in LDS, lane = row.  Rows e and f share the dofs
-        //      of depth <= lcad(chain_e, chain_f); yh is masked once per run of columns with the same chain.
+      if (small) {
+        // (7a) explicit A = Z Z' + diag(R), packed lower triangle in LDS, lane = row.  Rows e and f share the dofs
+        //      of depth <= lcad(chain_e, chain_f); the row is masked once per run of columns with the same chain.
         const bool isr = lane < nefc;
         const int je = isr ? lane : 0;
         const int tri = je * (je + 1) / 2;
+        const int chain = isr ? (int)CHN[je] - 1 : -1;
         {
           const int8_t* LCB = (const int8_t*)LC;
           const float Rj = EP[je * 8 + 2];
-          float ym[MAXD];
+          float zr[MAXD], zm[MAXD];
+          {
+            const float* yr = YC + je * RS;
 #pragma unroll
-          for (int dd = 0; dd < MAXD; dd++) ym[dd] = 0.f;
+            for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
+          }
+          WSYNC();            // AT overlays T/F, V/BUF, CI and cdof: every lane has its row before the first store
+#pragma unroll
+          for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
           int cprev = -2;
           for (int f = 0; f < nefc; f++) {
-            const int cf = __builtin_amdgcn_readlane(chain, f);
+            const int cf = (int)CHN[f] - 1;
             if (cf != cprev) {
               cprev = cf;
               const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
 #pragma unroll
-              for (int dd = 0; dd < MAXD; dd++) ym[dd] = dd <= l ? yh[dd] : 0.f;
+              for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
             }
             const float* yf = YC + f * RS;
             float a0 = 0.f;
 #pragma unroll
             for (int g4 = 0; g4 < MAXD / 4; g4++) {
               const float4 v = *(const float4*)(yf + 4 * g4);
-              a0 = fmaf(ym[4 * g4], v.x, a0); a0 = fmaf(ym[4 * g4 + 1], v.y, a0); a0 = fmaf(ym[4 * g4 + 2], v.z, a0); a0 = fmaf(ym[4 * g4 + 3], v.w, a0);
+              a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
             }
             if (isr && f <= je) AT[tri + f] = a0 + (f == je ? Rj : 0.f);
           }
@@ -1325,10 +1349,11 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         }
         float res = bj + afj;                                        // residual of row j: b + (A + R) f
         STAMP(18);  // warm start
-        // (8a) PGS on the explicit matrix.  Every lane keeps the update its own row would make from its current
-        //      residual (delta_j = max(-f_j, -res_j / A_jj), reverted if it would raise the cost by > 1e-10); row e's
-        //      turn is then one v_readlane of that value and one FMA on every residual: no reduction, no SGPR math.
-        //      Column e of the packed triangle for row j sits at max(tri(j) + e, tri(e) + j); fetched two rows ahead.
+        // (8a) PGS on the explicit matrix (mj_solPGS: rows in order, f_e <- max(0, f_e - res_e / A_ee), a row is
+        //      reverted if it would raise the cost by > 1e-10).  Every lane keeps the update its own row would make
+        //      from its current residual; row e's turn is then one v_readlane of that value and one FMA on every
+        //      residual: no reduction, no SGPR math.  Column e of the packed triangle for row j sits at
+        //      max(tri(j) + e, tri(e) + j); fetched two rows ahead.
         const float hdiag = 0.5f * diag;
         const float nainv = -ainv;
         float nf = -fj;
@@ -1356,51 +1381,144 @@ __global__ void __launch_bounds__(64, CONS ? 1 : 4) fmj_step_kernel(const DevMod
         if (isr) EP[je * 8 + 4] = fj;
         if (isd) {
           for (int e = 0; e < nefc; e++) {
-            const int ce = __builtin_amdgcn_readlane(chain, e);
+            const int ce = (int)CHN[e] - 1;
             const bool on = lane <= ce && ce < lane + dsub;
             w = fmaf(on ? YC[e * RS + ddepth] : 0.f, bcast(fj, e), w);
           }
-          w *= dinv_m;
+          w *= sqrtf(dinv_m);
         }
         WSYNC();
       } else {
-        // (7) more rows than lanes: matrix-free PGS.  A = Y D^-1 Y' is never formed; lanes hold w = D^-1 Y' f per dof
-        //     and a row residual is b_e + y_e.w + R_e f_e (one wave reduction per row).
-        for (int e = lane; e < nefc; e += 64) { float* ep = EP + e * 8; const float da = ep[0] + ep[2]; ep[5] = da; ep[0] = 1.0f / da; }
+        // (7b) more rows than the LDS matrix holds: A = Z Z' + diag(R) goes to the global scratch, full rows of
+        //      AG_LD floats (row f is written by the lanes that own rows e: A is symmetric, so the stores coalesce),
+        //      and each lane owns up to three rows (e = lane + 64 s).
+        float* AG = M.cons_a + (size_t)env * M.maxefc * AG_LD;
+        const int ns = (nefc + 63) >> 6;
+        const int8_t* LCB = (const int8_t*)LC;
+        for (int sl = 0; sl < ns; sl++) {
+          const int e = 64 * sl + lane;
+          const bool isr = e < nefc;
+          const int chain = isr ? (int)CHN[e] - 1 : -1;
+          const float Rj = isr ? EP[e * 8 + 2] : 0.f;
+          float zr[MAXD], zm[MAXD];
+          {
+            const float* yr = YC + (isr ? e : 0) * RS;
+#pragma unroll
+            for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
+          }
+#pragma unroll
+          for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
+          int cprev = -2;
+          for (int f = 0; f < nefc; f++) {
+            const int cf = (int)CHN[f] - 1;
+            if (cf != cprev) {
+              cprev = cf;
+              const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
+#pragma unroll
+              for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
+            }
+            const float* yf = YC + f * RS;
+            float a0 = 0.f;
+#pragma unroll
+            for (int g4 = 0; g4 < MAXD / 4; g4++) {
+              const float4 v = *(const float4*)(yf + 4 * g4);
+              a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
+            }
+            AG[(size_t)f * AG_LD + 64 * sl + lane] = a0 + (f == e ? Rj : 0.f);
+          }
+        }
+        __threadfence();
+        WSYNC();
+        STAMP(17);  // A
+        // per-lane row state (slot s = row lane + 64 s)
+        float res[3], nf[3], nainv[3], hdiag[3], bj[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) {
+          const int e = 64 * sl + lane;
+          const bool isr = e < nefc;
+          const float dg = isr ? AG[(size_t)e * AG_LD + e] : 1.f;
+          bj[sl] = isr ? EP[e * 8 + 3] : 0.f;
+          res[sl] = bj[sl]; nf[sl] = 0.f; nainv[sl] = -1.0f / dg; hdiag[sl] = 0.5f * dg;
+        }
+        // one pass over the rows: mode 0 applies the warm-start forces as given deltas (builds res = b + (A + R) f),
+        // mode 1 is a PGS sweep.  Rows of A are fetched PB rows ahead of their use.
+        constexpr int PB = 8;
+        float imp = 0.f;
+        float fw[3];
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) { const int e = 64 * sl + lane; fw[sl] = e < nefc ? EP[e * 8 + 4] : 0.f; }
+        for (int pass = -1; pass < M.solver_iterations; pass++) {
+          const int mode = pass < 0 ? 0 : 1;
+          imp = 0.f;
+
+          float cur[PB][3], nxt[PB][3];
+#pragma unroll
+          for (int r = 0; r < PB; r++) {
+            const int e = r < nefc ? r : nefc - 1;
+#pragma unroll
+            for (int sl = 0; sl < 3; sl++) cur[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f;
+          }
+          for (int e0 = 0; e0 < nefc; e0 += PB) {
+#pragma unroll
+            for (int r = 0; r < PB; r++) {
+              const int e = e0 + PB + r < nefc ? e0 + PB + r : nefc - 1;
+#pragma unroll
+              for (int sl = 0; sl < 3; sl++) nxt[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < PB; r++) {
+              const int e = e0 + r;
+              if (e < nefc) {
+                const int se = e >> 6, le = e & 63;
+                float dj, t = 0.f;
+                if (mode == 0) dj = se == 0 ? fw[0] : (se == 1 ? fw[1] : fw[2]);
+                else {
+                  const float rs_ = se == 0 ? res[0] : (se == 1 ? res[1] : res[2]);
+                  const float nf_ = se == 0 ? nf[0] : (se == 1 ? nf[1] : nf[2]);
+                  const float na_ = se == 0 ? nainv[0] : (se == 1 ? nainv[1] : nainv[2]);
+                  const float hd_ = se == 0 ? hdiag[0] : (se == 1 ? hdiag[1] : hdiag[2]);
+                  const float cand = fmaxf(nf_, rs_ * na_);
+                  t = fmaf(hd_, cand, rs_);
+                  dj = (cand * t > 1e-10f) ? 0.f : cand;
+                }
+                const float delta = bcast(dj, le);
+#pragma unroll
+                for (int sl = 0; sl < 3; sl++) res[sl] = fmaf(cur[r][sl], delta, res[sl]);
+                const float md = lane == le ? dj : 0.f;
+                if (se == 0) nf[0] -= md; else if (se == 1) nf[1] -= md; else nf[2] -= md;
+                imp = fmaf(md, t, imp);
+              }
+            }
+#pragma unroll
+            for (int r = 0; r < PB; r++)
+#pragma unroll
+              for (int sl = 0; sl < 3; sl++) cur[r][sl] = nxt[r][sl];
+          }
+          if (mode == 0) {   // dual cost of the warm start; start from f = 0 if that is better
+            float cost = 0.f;
+#pragma unroll
+            for (int sl = 0; sl < 3; sl++) cost += (-nf[sl]) * (0.5f * (res[sl] - bj[sl]) + bj[sl]);
+            cost = wave_sum_fast(cost);
+            if (cost > 0.f) {
+#pragma unroll
+              for (int sl = 0; sl < 3; sl++) { nf[sl] = 0.f; res[sl] = bj[sl]; }
+            }
+          } else {
+            const float improvement = -wave_sum_fast(imp);
+            if (improvement * M.pgs_scale < M.solver_tolerance) break;
+          }
+        }
+#pragma unroll
+        for (int sl = 0; sl < 3; sl++) { const int e = 64 * sl + lane; if (e < nefc) EP[e * 8 + 4] = -nf[sl]; }
+        __threadfence();
         WSYNC();
         if (isd) {
           for (int e = 0; e < nefc; e++) {
-            const int ce = ((__float_as_int(EP[e * 8 + 6]) >> 8) & 0xff) - 1;
+            const int ce = (int)CHN[e] - 1;
             const bool on = lane <= ce && ce < lane + dsub;
             w = fmaf(on ? YC[e * RS + ddepth] : 0.f, EP[e * 8 + 4], w);
           }
-          w *= dinv_m;
-        }
-        {   // dual cost of the warm start: sum_e f (0.5 R f + b) + 0.5 w' D w ; zero the start if f = 0 is better
-          float cost = isd ? 0.5f * w * w / dinv_m : 0.f;
-          for (int e = lane; e < nefc; e += 64) { const float* ep = EP + e * 8; cost += ep[4] * (0.5f * ep[2] * ep[4] + ep[3]); }
-          cost = wave_sum_fast(cost);
-          if (cost > 0.f) { w = 0.f; for (int e = lane; e < nefc; e += 64) EP[e * 8 + 4] = 0.f; }
-        }
-        WSYNC();
-        // (8) PGS (mj_solPGS): rows in order, f_e <- max(0, f_e - res/A_ee), revert a row if its cost change > 1e-10
-        for (int itp = 0; itp < M.solver_iterations; itp++) {
-          float improvement = 0.f;
-          for (int e = 0; e < nefc; e++) {
-            const float4 e0 = *(const float4*)(EP + e * 8);          // 1/A_ee, aref, R, b
-            const float4 e1 = *(const float4*)(EP + e * 8 + 4);      // force, diagA, type|chain|id, mu
-            const int ce = ((__float_as_int(e1.z) >> 8) & 0xff) - 1;
-            const float y = (isd && lane <= ce && ce < lane + dsub) ? YC[e * RS + ddepth] : 0.f;
-            const float res = e0.w + wave_sum_fast(y * w) + e0.z * e1.x;
-            float fnew = fmaxf(0.f, e1.x - res * e0.x);
-            float delta = fnew - e1.x;
-            float change = 0.5f * delta * delta * e1.y + delta * res;
-            if (change > 1e-10f) { fnew = e1.x; delta = 0.f; change = 0.f; }
-            improvement -= change;
-            w = fmaf(delta * dinv_m, y, w);
-            if (lane == 0) EP[e * 8 + 4] = fnew;
-          }
-          if (improvement * M.pgs_scale < M.solver_tolerance) break;
+          w *= sqrtf(dinv_m);
         }
         WSYNC();
       }
@@ -1958,6 +2076,18 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
   c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
   for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
+  D.cons_rows = nullptr; D.cons_a = nullptr;
+  if (D.cons && D.maxefc > 0) {   // HBM scratch of envs whose constraint rows outgrow LDS (fmj_step_kernel<.., CONS = true>, "big" path)
+    void* p1 = nullptr; void* p2 = nullptr;
+    if (hipMalloc(&p1, (size_t)n_envs * D.maxefc * 8 * sizeof(float)) != hipSuccess ||
+        hipMalloc(&p2, (size_t)n_envs * D.maxefc * AG_LD * sizeof(float)) != hipSuccess) {
+      if (p1) hipFree(p1);
+      fmj_destroy(c);
+      return set_err(FMJ_ERR_HIP, "fmj_create: out of device memory for the constraint scratch");
+    }
+    c->allocs.push_back(p1); c->allocs.push_back(p2);
+    D.cons_rows = (float*)p1; D.cons_a = (float*)p2;
+  }
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
   c->lds_bytes = (size_t)L.total * sizeof(float);
   c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
