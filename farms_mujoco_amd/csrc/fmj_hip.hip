@@ -1349,34 +1349,47 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         }
         float res = bj + afj;                                        // residual of row j: b + (A + R) f
         STAMP(18);  // warm start
-        // (8a) PGS on the explicit matrix (mj_solPGS: rows in order, f_e <- max(0, f_e - res_e / A_ee), a row is
-        //      reverted if it would raise the cost by > 1e-10).  Every lane keeps the update its own row would make
-        //      from its current residual; row e's turn is then one v_readlane of that value and one FMA on every
-        //      residual: no reduction, no SGPR math.  Column e of the packed triangle for row j sits at
-        //      max(tri(j) + e, tri(e) + j); fetched two rows ahead.
+        // (8a) PGS on the explicit matrix (mj_solPGS: rows in order, f_e <- max(0, f_e - res_e / A_ee)).  Every lane
+        //      keeps the update its own row would make from its current residual (delta_j = max(-f_j, -res_j / A_jj));
+        //      row e's turn is then one v_readlane of that value and one FMA on every residual: no reduction, no SGPR
+        //      math, a dependent chain of 4 VALU ops per row.  mj_solPGS reverts a row whose cost change
+        //      delta * (0.5 A_ee delta + res) exceeds 1e-10; for these scalar rows the two factors never have the
+        //      same sign, in floating point too (delta = -res/A_ee gives t = res/2; the clamped delta = -f gives
+        //      t >= res/2 > 0), so the revert cannot fire and is not evaluated; the product still feeds the
+        //      improvement that stops the sweeps.  Column e of the packed triangle for row j sits at
+        //      max(tri(j) + e, tri(e) + j); each column register is refilled right after its use.
         const float hdiag = 0.5f * diag;
         const float nainv = -ainv;
         float nf = -fj;
+        const int je4 = 4 * je, tri4 = 4 * tri;
+        const char* ATb = (const char*)AT;
+        // column c (uniform) of the packed triangle, byte address per lane; columns past the end read column 0
+#define PGS_COL(c) (*(const float*)(ATb + max(tri4 + 4 * ((c) < nefc ? (c) : 0), 2 * ((c) < nefc ? (c) : 0) * (((c) < nefc ? (c) : 0) + 1) + je4)))
+#define PGS_ROW(e_, acol_) do { \
+            float cand; asm("v_max_f32_e32 %0, %1, %2" : "=v"(cand) : "v"(nf), "v"(res * nainv)); /* no NaN canonicalisation */ \
+            const float t = fmaf(hdiag, cand, res);       /* cost change of the row = cand * t */ \
+            const float dj = cand; \
+            res = fmaf(acol_, bcast(dj, e_), res); \
+            float md; const unsigned long long bit_ = 1ull << (e_); \
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(md) : "v"(dj), "s"(bit_)); \
+            nf -= md; imp = fmaf(md, t, imp); } while (0)
         for (int itp = 0; itp < M.solver_iterations; itp++) {
           float imp = 0.f;
-          float acol = AT[tri], acol1 = AT[nefc > 1 ? max(tri + 1, 1 + je) : tri];
-          int tcol = 1;                                               // tri(e + 1)
-          for (int e = 0; e < nefc; e++) {
-            tcol += e + 2;                                            // tri(e + 2)
-            const float acol2 = AT[e + 2 < nefc ? max(tri + e + 2, tcol + je) : tri];
-            const float cand = fmaxf(nf, res * nainv);
-            const float t = fmaf(hdiag, cand, res);
-            const float delta_j = (cand * t > 1e-10f) ? 0.f : cand;
-            const float delta = bcast(delta_j, e);
-            res = fmaf(acol, delta, res);
-            const float md = lane == e ? delta_j : 0.f;
-            nf -= md;
-            imp = fmaf(md, t, imp);
-            acol = acol1; acol1 = acol2;
+          float a0 = PGS_COL(0), a1 = PGS_COL(1), a2 = PGS_COL(2), a3 = PGS_COL(3);
+          for (int e = 0; e < nefc; e += 4) {            // each column register is refilled right after its use: 3 rows of slack
+            PGS_ROW(e, a0); a0 = PGS_COL(e + 4);
+            if (e + 1 < nefc) PGS_ROW(e + 1, a1);
+            a1 = PGS_COL(e + 5);
+            if (e + 2 < nefc) PGS_ROW(e + 2, a2);
+            a2 = PGS_COL(e + 6);
+            if (e + 3 < nefc) PGS_ROW(e + 3, a3);
+            a3 = PGS_COL(e + 7);
           }
           const float improvement = -wave_sum_fast(imp);
           if (improvement * M.pgs_scale < M.solver_tolerance) break;
         }
+#undef PGS_ROW
+#undef PGS_COL
         fj = -nf;
         if (isr) EP[je * 8 + 4] = fj;
         if (isd) {
@@ -1479,7 +1492,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
                   const float hd_ = se == 0 ? hdiag[0] : (se == 1 ? hdiag[1] : hdiag[2]);
                   const float cand = fmaxf(nf_, rs_ * na_);
                   t = fmaf(hd_, cand, rs_);
-                  dj = (cand * t > 1e-10f) ? 0.f : cand;
+                  dj = cand;                                   // the revert of mj_solPGS cannot fire for scalar rows, see (8a)
                 }
                 const float delta = bcast(dj, le);
 #pragma unroll
