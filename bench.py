@@ -198,7 +198,7 @@ def main():
         traffic = None
         try:
             tr = json.load(open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')))
-            if tr['steps_per_launch'] == chunk and tr['envs'] == n_envs:
+            if tr['steps_per_launch'] == chunk and tr['envs'] == n_envs and tr.get('workload', 'swim') == args.workload:
                 traffic = tr['fetch_bytes'] + tr['write_bytes']
         except Exception:
             pass

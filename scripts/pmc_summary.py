@@ -28,6 +28,6 @@ for k in sorted(mean):
     if k.startswith('SQ_'):
         out.append(f'{k:<22s} per launch {mean[k]:>14.0f}   per wave-step ({waves} waves x {STEPS} steps) {mean[k]/(waves*STEPS):>9.1f}')
 open(f'profiles/r01_{tag}_pmc_summary.txt', 'w').write('\n'.join(out) + '\n')
-json.dump({'steps_per_launch': STEPS, 'envs': ENVS, 'fetch_bytes': fb, 'write_bytes': wb,
+json.dump({'workload': 'swim', 'steps_per_launch': STEPS, 'envs': ENVS, 'fetch_bytes': fb, 'write_bytes': wb,
            'source': f'profiles/r01_{tag}_pmc_summary.txt'}, open('profiles/latest_traffic.json', 'w'))
 print('\n'.join(out))
