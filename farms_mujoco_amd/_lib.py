@@ -61,6 +61,13 @@ class CFusedArgs(ctypes.Structure):
 
 
 # every symbol include/fmj.h declares: name -> (restype, argtypes)
+class CCpgDesc(ctypes.Structure):
+    _fields_ = [('n_osc', ctypes.c_int32), ('n_conn', ctypes.c_int32), ('nu', ctypes.c_int32),
+                ('frequency', _D), ('rate', _D), ('amplitude', _D),
+                ('conn_to', _I), ('conn_from', _I), ('conn_weight', _D), ('conn_bias', _D),
+                ('out_a', _I), ('out_b', _I), ('out_gain', _D), ('out_offset', _D)]
+
+
 SYMBOLS = {
     'fmj_create': (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.POINTER(_VP)]),
     'fmj_destroy': (None, [_VP]),
@@ -79,6 +86,9 @@ SYMBOLS = {
     'fmj_contacts2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits), _VP]),
     'fmj_step_fused': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CFusedArgs), _VP]),
     'fmj_sc': (ctypes.c_int, [ctypes.c_char_p]),
+    'fmj_cpg_create': (ctypes.c_int, [ctypes.POINTER(CCpgDesc), ctypes.c_int32, ctypes.POINTER(_VP)]),
+    'fmj_cpg_destroy': (None, [_VP]),
+    'fmj_cpg_tape': (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
 _lib = None

@@ -2299,6 +2299,111 @@ int fmj_contacts2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const
   return FMJ_OK;
 }
 
+// ---- oscillator-network controller (include/fmj.h: fmj_cpg_*) ---------------------------------------------------
+struct fmj_cpg {
+  int device, n_osc, n_conn, nu, max_deg;
+  float4* osc;      // [n_osc] 2 pi f, a, R, -
+  int* row;         // [n_osc + 1] CSR by target oscillator
+  float4* conn;     // [n_conn] from (bits), w, phi, -
+  float4* out;      // [nu] a (bits), b (bits), gain, offset
+};
+
+__global__ void __launch_bounds__(64) fmj_cpg_kernel(const int n_osc, const int nu, const float4* __restrict__ osc,
+                                                     const int* __restrict__ row, const float4* __restrict__ conn,
+                                                     const float4* __restrict__ outp, const int n_envs, const int n_steps,
+                                                     const float h, float* phase, float* amp, float* damp,
+                                                     const float* drive, float* tape) {
+  __shared__ float TH[64], RR[64];
+  const int env = blockIdx.x, lane = threadIdx.x;
+  const bool iso = lane < n_osc;
+  const int ol = iso ? lane : 0;
+  const float4 o = osc[ol];
+  const float dr = drive ? drive[env] : 1.f;
+  const float omega = o.x * dr, a = o.y, R = o.z;
+  const int k0 = row[ol], k1 = iso ? row[ol + 1] : k0;
+  float th = iso ? phase[(size_t)env * n_osc + lane] : 0.f;
+  float r = iso ? amp[(size_t)env * n_osc + lane] : 0.f;
+  float rd = iso ? damp[(size_t)env * n_osc + lane] : 0.f;
+  for (int s = 0; s < n_steps; s++) {
+    TH[lane] = th; RR[lane] = r;
+    __syncthreads();
+    float* t = tape + ((size_t)s * n_envs + env) * nu;
+    for (int u = lane; u < nu; u += 64) {
+      const float4 q = outp[u];
+      const int ia = __float_as_int(q.x), ib = __float_as_int(q.y);
+      float v = q.w;
+      if (ia >= 0) v += q.z * RR[ia] * (1.f + cosf(TH[ia]));
+      if (ib >= 0) v -= q.z * RR[ib] * (1.f + cosf(TH[ib]));
+      t[u] = v;
+    }
+    float dth = omega;
+    for (int k = k0; k < k1; k++) {
+      const float4 c = conn[k];
+      const int j = __float_as_int(c.x);
+      dth = fmaf(RR[j] * c.y, sinf(TH[j] - th - c.z), dth);
+    }
+    const float rdd = a * (0.25f * a * (R - r) - rd);
+    __syncthreads();
+    th = fmaf(h, dth, th);
+    r = fmaf(h, rd, r);
+    rd = fmaf(h, rdd, rd);
+    if (th > 3.14159265358979f) th -= 6.28318530717959f;        // only differences and cosines of phases are used
+  }
+  if (iso) { phase[(size_t)env * n_osc + lane] = th; amp[(size_t)env * n_osc + lane] = r; damp[(size_t)env * n_osc + lane] = rd; }
+}
+
+int fmj_cpg_create(const fmj_cpg_desc* d, int32_t device, fmj_cpg** out) {
+  if (!d || !out || d->n_osc < 1 || d->n_osc > 64 || d->n_conn < 0 || d->nu < 1) return set_err(FMJ_ERR_ARG, "fmj_cpg_create: need 1..64 oscillators, nu >= 1");
+  if (!d->frequency || !d->rate || !d->amplitude || !d->out_a || !d->out_b || !d->out_gain || !d->out_offset ||
+      (d->n_conn && (!d->conn_to || !d->conn_from || !d->conn_weight || !d->conn_bias))) return set_err(FMJ_ERR_ARG, "fmj_cpg_create: NULL array");
+  for (int k = 0; k < d->n_conn; k++)
+    if (d->conn_to[k] < 0 || d->conn_to[k] >= d->n_osc || d->conn_from[k] < 0 || d->conn_from[k] >= d->n_osc) return set_err(FMJ_ERR_ARG, "fmj_cpg_create: connection index out of range");
+  for (int u = 0; u < d->nu; u++)
+    if (d->out_a[u] >= d->n_osc || d->out_b[u] >= d->n_osc) return set_err(FMJ_ERR_ARG, "fmj_cpg_create: output oscillator out of range");
+  HIP_TRY(hipSetDevice(device));
+  std::vector<float4> osc(d->n_osc), conn(d->n_conn ? d->n_conn : 1), outp(d->nu);
+  std::vector<int> row(d->n_osc + 1, 0);
+  for (int i = 0; i < d->n_osc; i++) osc[i] = make_float4((float)(6.283185307179586 * d->frequency[i]), (float)d->rate[i], (float)d->amplitude[i], 0.f);
+  for (int k = 0; k < d->n_conn; k++) row[d->conn_to[k] + 1]++;
+  for (int i = 0; i < d->n_osc; i++) row[i + 1] += row[i];
+  { std::vector<int> fill(row.begin(), row.end() - 1);
+    for (int k = 0; k < d->n_conn; k++) conn[fill[d->conn_to[k]]++] = make_float4(ibits(d->conn_from[k]), (float)d->conn_weight[k], (float)d->conn_bias[k], 0.f); }
+  for (int u = 0; u < d->nu; u++) outp[u] = make_float4(ibits(d->out_a[u]), ibits(d->out_b[u]), (float)d->out_gain[u], (float)d->out_offset[u]);
+  fmj_cpg* c = new fmj_cpg();
+  c->device = device; c->n_osc = d->n_osc; c->n_conn = d->n_conn; c->nu = d->nu;
+  c->osc = nullptr; c->row = nullptr; c->conn = nullptr; c->out = nullptr;
+  bool ok = hipMalloc((void**)&c->osc, osc.size() * sizeof(float4)) == hipSuccess && hipMalloc((void**)&c->row, row.size() * sizeof(int)) == hipSuccess &&
+            hipMalloc((void**)&c->conn, conn.size() * sizeof(float4)) == hipSuccess && hipMalloc((void**)&c->out, outp.size() * sizeof(float4)) == hipSuccess;
+  ok = ok && hipMemcpy(c->osc, osc.data(), osc.size() * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(c->row, row.data(), row.size() * sizeof(int), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(c->conn, conn.data(), conn.size() * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(c->out, outp.data(), outp.size() * sizeof(float4), hipMemcpyHostToDevice) == hipSuccess;
+  if (!ok) { fmj_cpg_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_cpg_create: device allocation failed"); }
+  *out = c;
+  return FMJ_OK;
+}
+
+void fmj_cpg_destroy(fmj_cpg* c) {
+  if (!c) return;
+  (void)hipSetDevice(c->device);
+  if (c->osc) (void)hipFree(c->osc);
+  if (c->row) (void)hipFree(c->row);
+  if (c->conn) (void)hipFree(c->conn);
+  if (c->out) (void)hipFree(c->out);
+  delete c;
+}
+
+int fmj_cpg_tape(fmj_cpg* c, int32_t n_envs, int32_t n_steps, double timestep, float* phase, float* amp, float* damp,
+                 const float* drive, float* ctrl_tape, void* stream) {
+  if (!c || n_envs <= 0 || n_steps < 0 || !phase || !amp || !damp || !ctrl_tape) return set_err(FMJ_ERR_ARG, "fmj_cpg_tape: bad argument");
+  if (n_steps == 0) return FMJ_OK;
+  HIP_TRY(hipSetDevice(c->device));
+  hipLaunchKernelGGL(fmj_cpg_kernel, dim3(n_envs), dim3(64), 0, (hipStream_t)stream, c->n_osc, c->nu, c->osc, c->row, c->conn, c->out,
+                     n_envs, n_steps, (float)timestep, phase, amp, damp, drive, ctrl_tape);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
 int fmj_sc(const char* name) {
   static const struct { const char* n; int v; } tab[] = {
       {"LINK_COM_POS", FMJ_LINK_COM_POS}, {"LINK_COM_QUAT", FMJ_LINK_COM_QUAT}, {"LINK_URDF_POS", FMJ_LINK_URDF_POS},

@@ -108,12 +108,17 @@ class Simulation:
             a.water = h.water.as_c(use_buoyancy=h.buoyancy)
         a.units = task.units.as_c()
         c = task._controller
-        if c is not None:
+        cd = phys._cdata()
+        if c is not None and getattr(c, 'tape', False):        # device controller that hands over a ctrl tape
+            tape = c.ctrl_tape(n_steps)
+            a.controller = 0
+            a.ctrl_step_stride = tape.stride(0)
+            cd.ctrl = tape.data_ptr()
+        elif c is not None:
             a.controller = 1
             a.wave.amplitude, a.wave.phase_lag, a.wave.env_phase = (c.amplitude.data_ptr(), c.phase_lag.data_ptr(),
                                                                      c.env_phase.data_ptr())
             a.wave.frequency = c.frequency
-        cd = phys._cdata()
         _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
                                             ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
         task.iteration += n_steps

@@ -300,6 +300,37 @@ typedef struct fmj_fused_args {
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);
 
+/* ---- on-device controller: a network of amplitude-controlled phase oscillators --------------------
+ * The reference only defines the AnimatController interface (task.py:292-346: step/positions/torques/springrefs);
+ * the oscillator networks themselves live in its callers (farms_amphibious). This is the batched device counterpart:
+ *   theta_i' = 2 pi f_i + sum_k r_j(k) w_k sin(theta_j(k) - theta_i - phi_k)      (connections k into i)
+ *   r_i''    = a_i (a_i / 4 (R_i - r_i) - r_i')
+ * integrated with explicit Euler at the physics timestep, one wave per env, lane = oscillator (n_osc <= 64).
+ * Output u of nu:  ctrl_u = gain_u (r_a (1 + cos theta_a) - r_b (1 + cos theta_b)) + offset_u   (b < 0: single-sided)
+ * fmj_cpg_tape advances the network n_steps and writes ctrl_tape[s][env][u] of the state BEFORE each step, which is
+ * exactly what fmj_step / fmj_step_fused consume as a ctrl tape (controller 0, ctrl_step_stride = n_envs * nu). */
+typedef struct fmj_cpg_desc {
+  int32_t n_osc, n_conn, nu;
+  const double* frequency;    /* [n_osc] Hz */
+  const double* rate;         /* [n_osc] a_i */
+  const double* amplitude;    /* [n_osc] R_i */
+  const int32_t* conn_to;     /* [n_conn] i */
+  const int32_t* conn_from;   /* [n_conn] j */
+  const double* conn_weight;  /* [n_conn] w */
+  const double* conn_bias;    /* [n_conn] phi */
+  const int32_t* out_a;       /* [nu] oscillator a of output u (-1: output is offset only) */
+  const int32_t* out_b;       /* [nu] oscillator b or -1 */
+  const double* out_gain;     /* [nu] */
+  const double* out_offset;   /* [nu] */
+} fmj_cpg_desc;
+typedef struct fmj_cpg fmj_cpg;
+int fmj_cpg_create(const fmj_cpg_desc* desc, int32_t device, fmj_cpg** out);
+void fmj_cpg_destroy(fmj_cpg* cpg);
+/* phase, amp, damp: [n_envs][n_osc] DEVICE fp32 (updated in place); drive: [n_envs] DEVICE fp32 or NULL, scales the
+ * intrinsic frequencies per env; ctrl_tape: [n_steps][n_envs][nu] DEVICE fp32. */
+int fmj_cpg_tape(fmj_cpg* cpg, int32_t n_envs, int32_t n_steps, double timestep, float* phase, float* amp, float* damp,
+                 const float* drive, float* ctrl_tape, void* hip_stream);
+
 /* enum query so host code never hard-codes column integers: name is e.g. "LINK_COM_POS" */
 int fmj_sc(const char* name);
 

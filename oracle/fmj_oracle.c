@@ -1129,3 +1129,41 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
   free(th); free(jobs);
   return FMJ_OK;
 }
+
+/* ---- oscillator-network controller (include/fmj.h: fmj_cpg_desc / fmj_cpg_tape), fp64, explicit Euler.
+ * The reference holds only the AnimatController interface (task.py:292-346); this restates the build's own
+ * device controller so that the HIP kernel has a checker. */
+int fmjo_cpg_tape(const fmj_cpg_desc* d, int n_envs, int n_steps, double h, double* phase, double* amp, double* damp,
+                  const double* drive, double* tape) {
+  if (!d || d->n_osc < 1 || d->n_osc > 64) return FMJ_ERR_ARG;
+  const int no = d->n_osc, nu = d->nu;
+  const double PI = 3.14159265358979323846;
+  for (int e = 0; e < n_envs; e++) {
+    double* th = phase + (size_t)e * no; double* r = amp + (size_t)e * no; double* rd = damp + (size_t)e * no;
+    const double dr = drive ? drive[e] : 1.0;
+    for (int s = 0; s < n_steps; s++) {
+      double* t = tape + ((size_t)s * n_envs + e) * nu;
+      for (int u = 0; u < nu; u++) {
+        double v = d->out_offset[u];
+        if (d->out_a[u] >= 0) v += d->out_gain[u] * r[d->out_a[u]] * (1.0 + cos(th[d->out_a[u]]));
+        if (d->out_b[u] >= 0) v -= d->out_gain[u] * r[d->out_b[u]] * (1.0 + cos(th[d->out_b[u]]));
+        t[u] = v;
+      }
+      double dth[64];
+      for (int i = 0; i < no; i++) dth[i] = 2.0 * PI * d->frequency[i] * dr;
+      for (int k = 0; k < d->n_conn; k++) {
+        const int i = d->conn_to[k], j = d->conn_from[k];
+        dth[i] += r[j] * d->conn_weight[k] * sin(th[j] - th[i] - d->conn_bias[k]);
+      }
+      for (int i = 0; i < no; i++) {
+        const double a = d->rate[i];
+        const double rdd = a * (0.25 * a * (d->amplitude[i] - r[i]) - rd[i]);
+        const double nth = th[i] + h * dth[i];
+        r[i] += h * rd[i];
+        rd[i] += h * rdd;
+        th[i] = nth > PI ? nth - 2.0 * PI : nth;
+      }
+    }
+  }
+  return FMJ_OK;
+}

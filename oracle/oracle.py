@@ -180,3 +180,25 @@ def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer
     assert rc == 0, rc
     return dict(qpos=qpos, qvel=qvel, xpos=xpos, xquat=xquat, xipos=xipos, sensordata=sd, status=status,
                 links=links, joints=joints, xfrc=xfrc)
+
+
+class _CpgDesc(ctypes.Structure):
+    _fields_ = [('n_osc', ctypes.c_int32), ('n_conn', ctypes.c_int32), ('nu', ctypes.c_int32),
+                ('frequency', _D), ('rate', _D), ('amplitude', _D),
+                ('conn_to', _I), ('conn_from', _I), ('conn_weight', _D), ('conn_bias', _D),
+                ('out_a', _I), ('out_b', _I), ('out_gain', _D), ('out_offset', _D)]
+
+
+def cpg_tape(network, n_steps, timestep, phase, amp, damp, drive=None):
+    """fp64 restatement of fmj_cpg_tape: returns (tape[n_steps, n_envs, nu], phase, amp, damp) after n_steps."""
+    phase = _c64(phase).copy(); n = phase.shape[0]
+    amp = _c64(amp).reshape(n, -1).copy(); damp = _c64(damp).reshape(n, -1).copy()
+    tape = np.zeros((n_steps, n, network.nu))
+    d = network.as_c(_CpgDesc)
+    drv = None if drive is None else _c64(drive)
+    f = lib().fmjo_cpg_tape
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.POINTER(_CpgDesc), ctypes.c_int, ctypes.c_int, ctypes.c_double, _D, _D, _D, _D, _D]
+    rc = f(ctypes.byref(d), n, n_steps, float(timestep), _d(phase), _d(amp), _d(damp), _d(drv), _d(tape))
+    assert rc == 0, rc
+    return tape, phase, amp, damp

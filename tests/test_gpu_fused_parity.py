@@ -93,6 +93,34 @@ def test_fused_loop_matches_oracle(oracle, water_kwargs):
         assert dry.any() and (~dry).any()
 
 
+def test_fused_loop_with_network_controller(oracle):
+    """The fused launch consumes the ctrl tape the device oscillator network writes; rows and state
+    match the oracle stepping the oracle's own tape."""
+    import torch
+    from farms_mujoco_amd.control import salamander_network, NetworkController
+    n, T = 8, 200
+    sim, m, psi = _make_sim(n, T, buffer_size=50)
+    net = salamander_network(m)
+    ctl = NetworkController(m, net, n, env_phase=psi)
+    sim.task._controller = ctl
+    assert sim.task.fusable()
+    ph0, a0, d0 = (x.cpu().numpy().astype(np.float64) for x in (ctl.phase, ctl.amp, ctl.damp))
+    st = _oracle_initial_state(oracle, sim, m)
+    swim, water = _swim_water(sim)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    tape, *_ = oracle.cpg_tape(net, T, m.timestep, ph0, a0, d0)
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=50, controller=0, ctrl=tape,
+                           ctrl_step_stride=n*m.nu, n_threads=8)
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    sens = sim.task.data.sensors
+    errs = dict(qpos=_relerr(d.qpos.cpu().numpy(), ref['qpos']), links=_relerr(sens.links.array.cpu().numpy(), ref['links']))
+    print(errs)
+    assert errs['qpos'] < 1e-4 and errs['links'] < 1e-4, errs
+    assert np.abs(d.qpos.cpu().numpy()[:, 7:]).max() > 0.05            # the network does bend the spine
+
+
 def test_fused_equals_unfused_operators(oracle):
     """The fused launch and the operator-by-operator path (fmj_physics2data, fmj_drag, torch ctrl write,
     fmj_step) agree; the only difference is sin() evaluated by torch vs in-kernel sinf."""
