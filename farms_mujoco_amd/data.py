@@ -75,10 +75,49 @@ class AnimatData:
         return cls(timestep, buffer_size, n_envs, links, joints, device=device, **kwargs)
 
     def to_file(self, path, iteration=None):
-        """Post-hoc log (reference simulation.py:200-203 writes HDF5; h5py is absent here -> .npz)."""
+        """Post-hoc log (reference simulation.py:200-203: ``data.to_file('simulation.hdf5', iteration)``).
+        ``*.hdf5`` / ``*.h5`` are written with h5py when it is importable (one dataset per sensor array under
+        ``sensors/``, names as string attributes); otherwise, and for any other suffix, a compressed ``.npz`` with the
+        same keys.  Arrays are [iteration, n_envs, n, width]."""
         import numpy as np
         n = self.buffer_size if iteration is None else min(iteration, self.buffer_size)
-        np.savez_compressed(path, timestep=self.timestep,
-                            **{k: getattr(self.sensors, k).array[:n].cpu().numpy()
-                               for k in ('links', 'joints', 'xfrc', 'contacts')},
-                            links_names=self.sensors.links.names, joints_names=self.sensors.joints.names)
+        arrays = {k: getattr(self.sensors, k).array[:n].cpu().numpy() for k in ('links', 'joints', 'xfrc', 'contacts')}
+        names = {k: [str(x) for x in getattr(self.sensors, k).names] for k in arrays}
+        if str(path).endswith(('.hdf5', '.h5')):
+            try:
+                import h5py
+            except ImportError:
+                path = str(path).rsplit('.', 1)[0] + '.npz'
+            else:
+                with h5py.File(path, 'w') as f:
+                    f.attrs['timestep'] = self.timestep
+                    g = f.create_group('sensors')
+                    for k, a in arrays.items():
+                        ds = g.create_dataset(k, data=a, compression='gzip')
+                        ds.attrs['names'] = [str(x) for x in names[k]]
+                return path
+        np.savez_compressed(path, timestep=self.timestep, **arrays,
+                            **{f'{k}_names': np.array([str(x) for x in v]) for k, v in names.items()})
+        return path
+
+    @classmethod
+    def from_file(cls, path, device='cpu'):
+        """Load a log written by ``to_file`` (either container)."""
+        import numpy as np
+        if str(path).endswith(('.hdf5', '.h5')):
+            import h5py
+            with h5py.File(path, 'r') as f:
+                ts = float(f.attrs['timestep'])
+                arrays = {k: np.asarray(f['sensors'][k]) for k in f['sensors']}
+                names = {k: [n.decode() if isinstance(n, bytes) else str(n) for n in f['sensors'][k].attrs['names']] for k in f['sensors']}
+        else:
+            z = np.load(path, allow_pickle=False)
+            ts = float(z['timestep'])
+            arrays = {k: z[k] for k in ('links', 'joints', 'xfrc', 'contacts')}
+            names = {k: [str(n) for n in z[f'{k}_names']] for k in arrays}
+        n_it, n_envs = arrays['links'].shape[:2]
+        contacts = [tuple(c.strip("()' ").replace("'", '').split(', ')) if c.startswith('(') else c for c in names['contacts']]
+        out = cls(ts, n_it, n_envs, names['links'], names['joints'], xfrc=names['xfrc'], contacts=contacts, device=device)
+        for k, a in arrays.items():
+            getattr(out.sensors, k).array.copy_(torch.as_tensor(a))
+        return out

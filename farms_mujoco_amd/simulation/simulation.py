@@ -166,7 +166,7 @@ class Simulation:
         """Postprocessing after simulation (reference simulation.py:181-213)."""
         if log_path:
             pylog.info('Saving data to %s', log_path)
-            self.task.data.to_file(os.path.join(log_path, 'simulation.npz'), iteration)
+            self.task.data.to_file(os.path.join(log_path, 'simulation.hdf5'), iteration)   # .npz when h5py is absent
             self.options.save(os.path.join(log_path, 'simulation_options.yaml'))
             if self.task.animat_options is not None:
                 self.task.animat_options.save(os.path.join(log_path, 'animat_options.yaml'))

@@ -91,3 +91,22 @@ def test_synthetic_batch_is_keyed_by_global_index():
     q, v, psi = synthetic_batch(m, 12, seed=3)
     q2, v2, psi2 = synthetic_batch(m, 5, seed=3, env_offset=4)
     assert np.array_equal(q[4:9], q2) and np.array_equal(psi[4:9], psi2)
+
+
+def test_animat_data_log_round_trip(tmp_path):
+    """AnimatData.to_file / from_file (reference simulation.py:200-203 writes simulation.hdf5; .npz when h5py is
+    absent): arrays, names and the iteration cut survive."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    d = AnimatData(1e-3, 6, 3, ['a', 'b'], ['j0'], contacts=[('a', ''), ('b', 'a')], device='cpu')
+    g = torch.Generator().manual_seed(0)
+    for k in ('links', 'joints', 'xfrc', 'contacts'):
+        arr = getattr(d.sensors, k).array
+        arr.copy_(torch.rand(arr.shape, generator=g))
+    path = d.to_file(str(tmp_path/'simulation.hdf5'), iteration=4)
+    back = AnimatData.from_file(path)
+    assert back.timestep == 1e-3 and back.buffer_size == 4 and back.n_envs == 3
+    assert back.sensors.links.names == ['a', 'b'] and back.sensors.joints.names == ['j0']
+    for k in ('links', 'joints', 'xfrc', 'contacts'):
+        assert torch.equal(getattr(back.sensors, k).array, getattr(d.sensors, k).array[:4])
+    assert len(back.sensors.contacts.names) == 2
