@@ -223,7 +223,14 @@ __device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wa
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float pinf(float x) { asm volatile("" : "+v"(x)); return x; }
 // LDS ordering between lanes of the one wave that forms the workgroup
+// (every kernel here runs 64-thread workgroups = one wave: LDS operations of one wave execute in order, so ordering
+// between lanes needs no s_barrier and no s_waitcnt, only that the compiler keeps the program order)
+#ifdef FMJ_FULL_BARRIERS
 #define WSYNC() __syncthreads()
+#else
+#define WSYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#endif
 #define WSYNC_LOCAL() __builtin_amdgcn_wave_barrier()
 
 __device__ __forceinline__ void lds_put6(float* p, s6 v) {
