@@ -43,6 +43,16 @@ static int set_err(int code, const std::string& msg) { g_err = msg; return code;
 // ---------------------------------------------------------------------------------------------
 // device model (fp32 tables shared by all envs)
 
+// One elimination round of the two-env kernel: up to three lane dofs of the same depth (so none is an ancestor of
+// another), deepest level first.  Masks name lanes, the same 32-bit pattern in both halves.  Read through the scalar
+// cache (constant address space), one round ahead of its use.
+struct DualRound {
+  int p0, p1, p2, depth;              // lane dofs, their absolute depth; p1 = -1: single-member round; an absent third
+                                      // member repeats p0 under empty masks
+  unsigned long long anc[3];          // lanes whose dof is a proper ancestor of p_c
+  unsigned long long desc[3];         // lanes whose dof is a proper descendant of p_c
+};
+
 struct DevModel {
   int nbody, nv, nq, nu, njnt, nM, nMpad;
   int max_bdepth;     // pointer-jumping rounds = ceil(log2(longest root->body chain))
@@ -72,6 +82,8 @@ struct DevModel {
   int dual_ok, dual_t0, dual_nM;       // eligible, translational dofs carried as scalars (3 with a free root), padded entry count
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
   const float4* mtab2;                 // [dual_nM] entries (i, j >= dual_t0) in the mtab format
+  const struct DualRound* dual_rounds; // [dual_nround] elimination rounds of the two-env kernel (fmj_dual.inc)
+  int dual_nround;
 };
 
 
@@ -2091,6 +2103,38 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     D.dual_nM = (int)mtab2.size();
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
     UP(mtab2, mtab2);
+    {   // elimination rounds: lane dofs grouped by depth, deepest first, at most three per round
+      const int nd = nv - t0 > 0 ? nv - t0 : 0;
+      std::vector<DualRound> rounds;
+      if (D.dual_ok) {
+        std::vector<unsigned long long> ancm(nd, 0ull), descm(nd, 0ull);
+        int maxdep = 0;
+        for (int i = 0; i < nd; i++) {
+          if (ddepth[i + t0] > maxdep) maxdep = ddepth[i + t0];
+          for (int a = m->dof_parentid[i + t0]; a >= t0; a = m->dof_parentid[a]) {
+            ancm[i] |= (1ull << (a - t0)) | (1ull << (a - t0 + 32));
+            descm[a - t0] |= (1ull << i) | (1ull << (i + 32));
+          }
+        }
+        for (int dep = maxdep; dep >= 0; dep--) {
+          std::vector<int> lvl;
+          for (int i = 0; i < nd; i++) if (ddepth[i + t0] == dep) lvl.push_back(i);
+          for (size_t q = 0; q < lvl.size(); q += 3) {
+            DualRound R; memset(&R, 0, sizeof R);
+            int* pp[3] = {&R.p0, &R.p1, &R.p2};
+            R.depth = dep;
+            for (int c = 0; c < 3; c++) {
+              if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; R.desc[c] = descm[pv]; }
+              else *pp[c] = c == 1 ? -1 : R.p0;
+            }
+            rounds.push_back(R);
+          }
+        }
+      }
+      D.dual_nround = (int)rounds.size();
+      if (rounds.empty()) { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; rounds.push_back(R); }
+      UP(rounds, dual_rounds);
+    }
   }
   c->d_btab = (float4*)D.btab; c->d_dtab = (float4*)D.dtab;
   { std::vector<float4> empty4(ST_STRIDE, f4(0, 0, 0, 0)); UP(empty4, stab); }
