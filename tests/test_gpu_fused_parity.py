@@ -254,3 +254,60 @@ def _SdfWave(m, psi):
     c.amplitude = torch.as_tensor(amp, dtype=torch.float32, device='cuda:0')
     c.phase_lag = torch.as_tensor(lag, dtype=torch.float32, device='cuda:0')
     return c
+
+
+def test_full_size_config2_properties(oracle):
+    """BASELINE configs[1] at full size (4096 envs x 1000 fused steps, ring of 100 rows): no warning bits; envs with
+    identical inputs give bitwise identical rows wherever they sit in the batch (both halves of a wave, first and last
+    workgroup); the second half of the batch run on its own reproduces the full run bitwise (sharding invariance,
+    SURVEY 8e); a sample of envs matches the fp64 oracle to the north-star tolerance."""
+    import torch
+    from farms_mujoco_amd.model import salamander33, synthetic_batch
+    from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
+    from farms_mujoco_amd.control import WaveController
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    m = salamander33()
+    N, T, ring = 4096, 1000, 100
+    qpos, qvel, psi = synthetic_batch(m, N)
+    twins = [1, 2049, 4095]                       # copies of env 0
+    for e in twins:
+        qpos[e] = qpos[0]; qvel[e] = qvel[0]; psi[e] = psi[0]
+
+    def run(sl):
+        n = sl.stop - sl.start
+        sim = Simulation.from_sdf(SimulationOptions(timestep=m.timestep, n_iterations=T), AnimatOptions.from_model(m),
+                                  ArenaOptions(water=WaterOptions(height=0.0, drag=True, buoyancy=True, viscosity=1.0)),
+                                  model=m, n_envs=n, controller=WaveController(m, psi[sl]), buffer_size=ring)
+        sim.reset()
+        d = sim.physics.data
+        d.qpos[:] = torch.as_tensor(qpos[sl], dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel[sl], dtype=torch.float32)
+        sim.physics.forward(disable_actuation=True)
+        st = _oracle_initial_state(oracle, sim, m) if n <= 64 else None
+        sim.run(fused=True)
+        torch.cuda.synchronize()
+        return sim, st
+
+    sim, _ = run(slice(0, N))
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    q = d.qpos.cpu().numpy(); links = sim.task.data.sensors.links.array.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(links).all()
+    for e in twins:
+        assert np.array_equal(q[e], q[0]) and np.array_equal(links[:, e], links[:, 0])
+    half, _ = run(slice(N//2, N))
+    assert np.array_equal(half.physics.data.qpos.cpu().numpy(), q[N//2:])
+    assert np.array_equal(half.task.data.sensors.links.array.cpu().numpy(), links[:, N//2:])
+    # sample vs oracle: the first 8 envs stepped by the fp64 restatement from the same fp32 inputs
+    small, st = run(slice(0, 8))
+    assert np.array_equal(small.physics.data.qpos.cpu().numpy(), q[:8])
+    swim, water = _swim_water(small)
+    c = small.task._controller
+    wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
+                env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency)
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=ring, controller=1, wave=wave, n_threads=8)
+    err = _relerr(q[:8], ref['qpos'])
+    print('full-size sample qpos rel err after 1000 steps:', err)
+    assert err < 1e-4, err
+    assert _relerr(links[:, :8], ref['links']) < 2e-4
+    # the animals did swim: forward displacement of the root along -x/+x beyond a body width
+    assert np.abs(q[:, 0] - qpos[:, 0]).mean() > 0.02
