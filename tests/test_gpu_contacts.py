@@ -247,3 +247,41 @@ def test_fused_walk_with_contact_rows(oracle):
     c = sim_f.task.data.sensors.contacts.array.cpu().numpy()
     assert np.abs(c[T - 1][..., 2]).max() > 0.05          # the feet carry weight at the end (reaction z)
     assert np.array_equal(sim_f.physics.data.qpos.cpu().numpy(), sim_u.physics.data.qpos.cpu().numpy())
+
+
+def test_full_size_config4_properties(oracle):
+    """BASELINE configs[3] at full size (4096 walking envs x 100 fused steps): no warning bits, contact forces are
+    non-negative along the normal, nobody sinks through the floor, envs with identical inputs give bitwise identical
+    states and contact rows wherever they sit, and the second half of the batch run alone reproduces the full run."""
+    import torch
+    import bench
+    N, T = 4096, 100
+    twins = [1, 778, 2047]                 # copies of env 0, all in the first half of the batch
+
+    def run(n, off):
+        sim, m, _ = bench.build_sim(n, T, T, off, 'cuda:0', 'walk')
+        d = sim.physics.data
+        c = sim.task._controller
+        if off == 0:
+            for e in twins:
+                d.qpos[e] = d.qpos[0]; d.qvel[e] = d.qvel[0]; c.env_phase[e] = c.env_phase[0]
+        d.qacc_warmstart.zero_()            # the PGS warm start is state too: twins must share its history
+        sim.physics.forward(disable_actuation=True)
+        sim.run(fused=True)
+        torch.cuda.synchronize()
+        return sim
+
+    sim = run(N, 0)
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    q = d.qpos.cpu().numpy(); rows = sim.task.data.sensors.contacts.array.cpu().numpy()
+    ncon = d.ncon.cpu().numpy(); con = d.contact.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(rows).all()
+    assert ncon.min() >= 1 and ncon.max() <= 32 and q[:, 2].min() > 0.0
+    for e in range(0, N, 97):
+        assert (con[e, :ncon[e], 12] >= -1e-6).all()                      # normal force of every listed contact
+    for e in twins:
+        assert np.array_equal(q[e], q[0]) and np.array_equal(rows[:, e], rows[:, 0])
+    half = run(N//2, N//2)
+    assert np.array_equal(half.physics.data.qpos.cpu().numpy(), q[N//2:])
+    assert np.array_equal(half.task.data.sensors.contacts.array.cpu().numpy(), rows[:, N//2:])
