@@ -100,7 +100,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     stale = (not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src)
              or os.path.getmtime(SO_PATH) < os.path.getmtime(HEADER))
     if force or stale:
-        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-fPIC', '-shared', src, '-o', SO_PATH]
+        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC', '-shared', src, '-o', SO_PATH]
         if verbose:
             cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
         subprocess.check_call(cmd)

@@ -351,6 +351,7 @@ struct LdsLayout {
   int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
 };
 #define AG_LD 192      // row length of the global PGS matrix (three 64-lane slots)
+#define FMJ_NA 60      // constraint rows handled with one row per lane and A in registers
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
                                                 int maxcon = 0, int nvs = 0) {
   LdsLayout L;
@@ -378,17 +379,14 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
     L.LC = o; o += r4((nv * nv + 3) / 4);        // int8 [nv][nv]: depth of the deepest dof two chains share (-1: none)
     L.CH = o; o += r4((maxefc + 3) / 4);         // uint8 per row: last dof of the row's chain + 1
-    // Rows.  Up to na rows ("small") everything is in LDS: YJ = na compact rows, EP = their parameters, AT = packed
-    // triangle of A, which also covers T/F, V/BUF, CI and cdof (dead once the Jacobian rows exist).  With more rows
-    // the row vectors alone take YJ..CI (cdof is still read while they are written), parameters and A live in HBM.
-    L.na = maxefc < 60 ? maxefc : 60;
+    // Rows.  Up to na rows ("small") everything is on chip: YJ = na compact rows, EP = their parameters, A in
+    // registers (one row per lane).  With more rows the row vectors alone take YJ, EP, AT and the dead T/F, V/BUF, CI
+    // (cdof is still read while they are written); parameters and A live in HBM.
+    L.na = maxefc < FMJ_NA ? maxefc : FMJ_NA;
     L.YJ = o; o += L.na * rs;
     L.EP = o; o += L.na * 8;
-    const int tri = r4(L.na * (L.na + 1) / 2);
-    atx = tri - (dead + nv * 8); if (atx < 0) atx = 0;
     const int big = r4(maxefc * rs) - (L.na * rs + L.na * 8 + dead);      // floats the spilled rows need beyond YJ, EP, dead
-    if (atx < big) atx = big;
-    atx = r4(atx);
+    atx = r4(big > 0 ? big : 0);
     L.AT = o; o += atx;
   }
   L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
@@ -1314,12 +1312,14 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       STAMP(16);  // row params + Z
       float w = 0.f;
       if (small) {
-        // (7a) explicit A = Z Z' + diag(R), packed lower triangle in LDS, lane = row.  Rows e and f share the dofs
-        //      of depth <= lcad(chain_e, chain_f); the row is masked once per run of columns with the same chain.
+        // (7a) explicit A = Z Z' + diag(R), lane = row: lane j keeps row j of A in FMJ_NA registers (A is symmetric, so
+        //      this is also column j).  Rows e and f share the dofs of depth <= lcad(chain_e, chain_f); the lane's row
+        //      of Z is masked once per run of columns with the same chain (the 4 rows of a contact).  The column loop
+        //      is unrolled so that every register index is static; it leaves at the first column >= nefc.
         const bool isr = lane < nefc;
         const int je = isr ? lane : 0;
-        const int tri = je * (je + 1) / 2;
         const int chain = isr ? (int)CHN[je] - 1 : -1;
+        float areg[FMJ_NA];
         {
           const int8_t* LCB = (const int8_t*)LC;
           const float Rj = EP[je * 8 + 2];
@@ -1329,40 +1329,42 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
             for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
           }
-          WSYNC();            // AT overlays T/F, V/BUF, CI and cdof: every lane has its row before the first store
 #pragma unroll
           for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
           int cprev = -2;
-          for (int f = 0; f < nefc; f++) {
-            const int cf = (int)CHN[f] - 1;
-            if (cf != cprev) {
-              cprev = cf;
-              const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
 #pragma unroll
-              for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
-            }
-            const float* yf = YC + f * RS;
-            float a0 = 0.f;
+          for (int f = 0; f < FMJ_NA; f++) {
+            areg[f] = 0.f;
+            if (f < nefc) {
+              const int cf = __builtin_amdgcn_readlane(chain, f);
+              if (cf != cprev) {
+                cprev = cf;
+                const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
 #pragma unroll
-            for (int g4 = 0; g4 < MAXD / 4; g4++) {
-              const float4 v = *(const float4*)(yf + 4 * g4);
-              a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
+                for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
+              }
+              const float* yf = YC + f * RS;
+              float a0 = f == je ? Rj : 0.f;
+#pragma unroll
+              for (int g4 = 0; g4 < MAXD / 4; g4++) {
+                const float4 v = *(const float4*)(yf + 4 * g4);
+                a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
+              }
+              areg[f] = a0;
             }
-            if (isr && f <= je) AT[tri + f] = a0 + (f == je ? Rj : 0.f);
           }
         }
-        WSYNC();
         STAMP(17);  // A
         // warm start: keep it only if its dual cost beats f = 0 (mj_fwdConstraint)
         float fj = isr ? EP[je * 8 + 4] : 0.f;
         const float bj = isr ? EP[je * 8 + 3] : 0.f;
-        const float diag = isr ? AT[tri + je] : 1.f;
+        float diag = 1.f;                                            // A_jj + R_j: the lane's own column of its row
+#pragma unroll
+        for (int f = 0; f < FMJ_NA; f++) diag = (f == lane && isr) ? areg[f] : diag;
         const float ainv = 1.0f / diag;
         float afj = 0.f;
-        for (int k = 0; k < nefc; k++) {
-          const float akj = AT[k <= je ? tri + k : k * (k + 1) / 2 + je];
-          afj = fmaf(isr ? akj : 0.f, bcast(fj, k), afj);
-        }
+#pragma unroll
+        for (int k = 0; k < FMJ_NA; k++) if (k < nefc) afj = fmaf(areg[k], bcast(fj, k), afj);
         {
           const float cost = wave_sum_fast(fj * (0.5f * afj + bj));
           if (cost > 0.f) { fj = 0.f; afj = 0.f; }
@@ -1371,45 +1373,37 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         STAMP(18);  // warm start
         // (8a) PGS on the explicit matrix (mj_solPGS: rows in order, f_e <- max(0, f_e - res_e / A_ee)).  Every lane
         //      keeps the update its own row would make from its current residual (delta_j = max(-f_j, -res_j / A_jj));
-        //      row e's turn is then one v_readlane of that value and one FMA on every residual: no reduction, no SGPR
-        //      math, a dependent chain of 4 VALU ops per row.  mj_solPGS reverts a row whose cost change
-        //      delta * (0.5 A_ee delta + res) exceeds 1e-10; for these scalar rows the two factors never have the
-        //      same sign, in floating point too (delta = -res/A_ee gives t = res/2; the clamped delta = -f gives
-        //      t >= res/2 > 0), so the revert cannot fire and is not evaluated; the product still feeds the
-        //      improvement that stops the sweeps.  Column e of the packed triangle for row j sits at
-        //      max(tri(j) + e, tri(e) + j); each column register is refilled right after its use.
+        //      row e's turn is then one v_readlane of that value and one FMA of every residual with the lane's
+        //      register e: no reduction, no LDS, no address arithmetic, a dependent chain of 4 VALU ops per row.
+        //      mj_solPGS reverts a row whose cost change delta * (0.5 A_ee delta + res) exceeds 1e-10; for these scalar
+        //      rows the two factors never have the same sign, in floating point too (delta = -res/A_ee gives
+        //      t = res/2; the clamped delta = -f gives t >= res/2 > 0), so the revert cannot fire and is not
+        //      evaluated; the product still feeds the improvement that stops the sweeps.
         const float hdiag = 0.5f * diag;
         const float nainv = -ainv;
         float nf = -fj;
-        const int je4 = 4 * je, tri4 = 4 * tri;
-        const char* ATb = (const char*)AT;
-        // column c (uniform) of the packed triangle, byte address per lane; columns past the end read column 0
-#define PGS_COL(c) (*(const float*)(ATb + max(tri4 + 4 * ((c) < nefc ? (c) : 0), 2 * ((c) < nefc ? (c) : 0) * (((c) < nefc ? (c) : 0) + 1) + je4)))
-#define PGS_ROW(e_, acol_) do { \
-            float cand; asm("v_max_f32_e32 %0, %1, %2" : "=v"(cand) : "v"(nf), "v"(res * nainv)); /* no NaN canonicalisation */ \
-            const float t = fmaf(hdiag, cand, res);       /* cost change of the row = cand * t */ \
-            const float dj = cand; \
-            res = fmaf(acol_, bcast(dj, e_), res); \
-            float md; const unsigned long long bit_ = 1ull << (e_); \
-            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(md) : "v"(dj), "s"(bit_)); \
-            nf -= md; imp = fmaf(md, t, imp); } while (0)
-        for (int itp = 0; itp < M.solver_iterations; itp++) {
-          float imp = 0.f;
-          float a0 = PGS_COL(0), a1 = PGS_COL(1), a2 = PGS_COL(2), a3 = PGS_COL(3);
-          for (int e = 0; e < nefc; e += 4) {            // each column register is refilled right after its use: 3 rows of slack
-            PGS_ROW(e, a0); a0 = PGS_COL(e + 4);
-            if (e + 1 < nefc) PGS_ROW(e + 1, a1);
-            a1 = PGS_COL(e + 5);
-            if (e + 2 < nefc) PGS_ROW(e + 2, a2);
-            a2 = PGS_COL(e + 6);
-            if (e + 3 < nefc) PGS_ROW(e + 3, a3);
-            a3 = PGS_COL(e + 7);
-          }
-          const float improvement = -wave_sum_fast(imp);
-          if (improvement * M.pgs_scale < M.solver_tolerance) break;
+        // Rows past nefc are no-ops by construction (their lanes hold res = 0, f = 0 and a zero row), so the sweep is
+        // straight-line code for the next multiple of 12 rows: static register indices, one branch per step.
+#define PGS_SWEEPS(NR_) \
+        for (int itp = 0; itp < M.solver_iterations; itp++) { \
+          float imp = 0.f; \
+          _Pragma("unroll") for (int e = 0; e < NR_; e++) { \
+            float cand; asm("v_max_f32_e32 %0, %1, %2" : "=v"(cand) : "v"(nf), "v"(res * nainv));   /* no NaN canonicalisation */ \
+            const float t = fmaf(hdiag, cand, res);                   /* cost change of the row = cand * t */ \
+            res = fmaf(areg[e], bcast(cand, e), res); \
+            float md; const unsigned long long bit_ = 1ull << e; \
+            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(md) : "v"(cand), "s"(bit_)); \
+            nf -= md; imp = fmaf(md, t, imp); \
+          } \
+          const float improvement = -wave_sum_fast(imp); \
+          if (improvement * M.pgs_scale < M.solver_tolerance) break; \
         }
-#undef PGS_ROW
-#undef PGS_COL
+        if (nefc <= 12) { PGS_SWEEPS(12) }
+        else if (nefc <= 24) { PGS_SWEEPS(24) }
+        else if (nefc <= 36) { PGS_SWEEPS(36) }
+        else if (nefc <= 48) { PGS_SWEEPS(48) }
+        else { PGS_SWEEPS(FMJ_NA) }
+#undef PGS_SWEEPS
         fj = -nf;
         if (isr) EP[je * 8 + 4] = fj;
         if (isd) {
