@@ -84,6 +84,8 @@ struct DevModel {
   const float4* mtab2;                 // [dual_nM] entries (i, j >= dual_t0) in the mtab format
   const struct DualRound* dual_rounds; // [dual_nround] elimination rounds of the two-env kernel (fmj_dual.inc)
   int dual_nround;
+  const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
+  int nround1;
 };
 
 
@@ -433,9 +435,18 @@ __device__ __forceinline__ double subtree_sum_f64(double x, int last) {
 // tracked in its own register so D_k comes from a v_readlane before the LDS round trip.  Slots past a lane's
 // depth only ever hold finite garbage that is never read as a matrix entry (the caller zero-fills HR before
 // assembling the matrix).  On return HR holds the final rows (L*D) and dinv = 1/D_lane.
+// v where the lane's bit in the (uniform) mask is set, else 0
+__device__ __forceinline__ float mask_select(const float v, const unsigned long long m) {
+  float r;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(v), "s"(m));
+  return r;
+}
+
+typedef const DualRound __attribute__((address_space(4)))* cround_p;   // constant address space: uniform index -> s_load
+
 typedef float f2_t __attribute__((ext_vector_type(2)));
 template <int MAXD>
-__device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int ddepth, int dsub, int nv, float& dinv_mine) {
+__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int lane, bool isd, int ddepth, float& dinv_mine) {
   constexpr int RS = MAXD;
   f2_t r[MAXD / 2];                                // row in registers as float pairs: the update is v_pk_fma_f32
 #pragma unroll
@@ -445,35 +456,44 @@ __device__ __forceinline__ void ldl_factor(float* HR, int lane, bool isd, int dd
     r[d / 2] = f2_t{t.x, t.y}; r[d / 2 + 1] = f2_t{t.z, t.w};
   }
   float diag = isd ? HR[lane * RS + ddepth] : 1.f;
-  dinv_mine = 0.f;
+  // Rounds of unrelated dofs (same depth, deepest level first, <= 3 per round; records built at fmj_create and read
+  // through the scalar cache one round ahead): every lane publishes its working row and 1/diag (DV) - only the
+  // members' are read, theirs are final - and every proper ancestor i of a member k (uniform lane mask) does
+  // row_i -= (row_k[depth_i] / D_k) row_k.  One LDS round trip per tree level instead of one per dof.
+  const cround_p RND = (cround_p)rounds;
+#define APPLY_PIVOT(p_, am_) do { \
+    const float tk_ = HR[(p_) * RS + ddepth]; const float dki_ = DV[p_]; \
+    float4 rk_[MAXD / 4]; \
+    _Pragma("unroll") for (int g = 0; g < MAXD / 4; g++) rk_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); \
+    const float t_ = mask_select(tk_ * dki_, am_); \
+    const f2_t nt_ = f2_t{-t_, -t_}; \
+    _Pragma("unroll") for (int g = 0; g < MAXD / 4; g++) { \
+      r[2 * g] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].x, rk_[g].y}, r[2 * g]); \
+      r[2 * g + 1] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].z, rk_[g].w}, r[2 * g + 1]); } \
+    diag = fmaf(-t_, tk_, diag); } while (0)
+  {
+    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2;
+    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
 #pragma unroll 1
-  for (int k = nv - 1; k >= 0; k--) {
-    const float Dk = bcast(diag, k);
-    float dk_inv = __builtin_amdgcn_rcpf(Dk);
-    dk_inv = dk_inv * (2.0f - Dk * dk_inv);          // one Newton step: full fp32 accuracy
-    if (lane == k) {
-      dinv_mine = dk_inv;
+    for (int rd = 0; rd < nround; rd++) {
+      const int rn = rd + 1 < nround ? rd + 1 : rd;
+      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2;
+      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2];
+      if (isd) {
 #pragma unroll
-      for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y);
+        for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y);
+        DV[lane] = __builtin_amdgcn_rcpf(diag);
+      }
+      WSYNC();
+      APPLY_PIVOT(p0, a0);
+      if (p1 >= 0) { APPLY_PIVOT(p1, a1); APPLY_PIVOT(p2, a2); }
+      WSYNC();
+      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2;
     }
-    WSYNC();
-    const float tk = HR[k * RS + ddepth];
-    float4 rk[MAXD / 4];
-#pragma unroll
-    for (int g = 0; g < MAXD / 4; g++) rk[g] = *(const float4*)(HR + k * RS + 4 * g);
-    const bool anc = lane < k && k < lane + dsub;
-    const float t = anc ? tk * dk_inv : 0.f;
-    const f2_t nt = f2_t{-t, -t};
-    // all groups, unconditionally: straight-line code beats skipping the (on average 40 %) padding groups
-#pragma unroll
-    for (int g = 0; g < MAXD / 4; g++) {
-      r[2 * g] = __builtin_elementwise_fma(nt, f2_t{rk[g].x, rk[g].y}, r[2 * g]);
-      r[2 * g + 1] = __builtin_elementwise_fma(nt, f2_t{rk[g].z, rk[g].w}, r[2 * g + 1]);
-    }
-    diag = fmaf(-t, tk, diag);
-    WSYNC();
   }
-  // every lane's register row is final since its own pivot turn: publish it once more, scaled by 1/D, so that
+#undef APPLY_PIVOT
+  dinv_mine = isd ? __builtin_amdgcn_rcpf(diag) : 0.f;
+  // every lane's register row is final since its own round: publish it once more, scaled by 1/D, so that
   // HR holds the unit-triangular factor L itself (diagonal slot = 1) and the solves need no per-entry scaling
   if (isd) {
 #pragma unroll
@@ -1123,7 +1143,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (1) factor M, qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
       {
-        ldl_factor<MAXD>(HM, lane, isd, ddepth, dsub, nv, dinv_m);
+        ldl_factor<MAXD>(HM, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_m);
       }
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); }
@@ -1598,7 +1618,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     float my_qacc;
     {
       float dinv_mine;
-      ldl_factor<MAXD>(HR, lane, isd, ddepth, dsub, nv, dinv_mine);
+      ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_mine);
       STAMP(9);   // L
       my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine);
     }
@@ -2097,6 +2117,31 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     D.dual_nM = (int)mtab2.size();
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
     UP(mtab2, mtab2);
+    {   // elimination rounds of the one-env kernel (lane = dof): dofs grouped by depth, deepest first, <= 3 per round
+      std::vector<DualRound> rounds;
+      std::vector<unsigned long long> ancm(nv, 0ull), descm(nv, 0ull);
+      int maxdep = 0;
+      for (int i = 0; i < nv; i++) {
+        if (ddepth[i] > maxdep) maxdep = ddepth[i];
+        for (int a = m->dof_parentid[i]; a >= 0; a = m->dof_parentid[a]) { ancm[i] |= 1ull << a; descm[a] |= 1ull << i; }
+      }
+      for (int dep = maxdep; dep >= 0; dep--) {
+        std::vector<int> lvl;
+        for (int i = 0; i < nv; i++) if (ddepth[i] == dep) lvl.push_back(i);
+        for (size_t q = 0; q < lvl.size(); q += 3) {
+          DualRound R; memset(&R, 0, sizeof R);
+          int* pp[3] = {&R.p0, &R.p1, &R.p2};
+          R.depth = dep;
+          for (int c = 0; c < 3; c++) {
+            if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; R.desc[c] = descm[pv]; }
+            else *pp[c] = c == 1 ? -1 : R.p0;
+          }
+          rounds.push_back(R);
+        }
+      }
+      D.nround1 = (int)rounds.size();
+      UP(rounds, rounds1);
+    }
     {   // elimination rounds: lane dofs grouped by depth, deepest first, at most three per round
       const int nd = nv - t0 > 0 ? nv - t0 : 0;
       std::vector<DualRound> rounds;
