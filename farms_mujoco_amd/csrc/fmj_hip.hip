@@ -1573,19 +1573,41 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (9) qfrc_constraint = J' f = L'(Y' f) ; qacc = qacc_smooth + L^-1 w  (saved as next step's warm start)
       {
         const float u = isd ? w / dinv_m : 0.f;                      // (Y' f)_d
-        float q = u;
-        for (int i = nv - 1; i >= 1; i--) {
-          const float ui = bcast(u, i);
-          const bool anc = lane < i && i < lane + dsub;
-          q = fmaf(anc ? HM[i * RS + ddepth] : 0.f, ui, q);
+        float q = u;                                                 // q_a = u_a + sum over descendants i of L[i][a] u_i: no chain, LDS reads batched
+        {
+          int i = nv - 1;
+          for (; i >= 8; i -= 8) {
+            float l[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) l[k] = HM[(i - k) * RS + ddepth];
+#pragma unroll
+            for (int k = 0; k < 8; k++) { const bool anc = lane < i - k && i - k < lane + dsub; q = fmaf(anc ? l[k] : 0.f, bcast(u, i - k), q); }
+          }
+#pragma unroll 1
+          for (; i >= 1; i--) { const bool anc = lane < i && i < lane + dsub; q = fmaf(anc ? HM[i * RS + ddepth] : 0.f, bcast(u, i), q); }
         }
         qfrc_c = q;
-        float xa = w;
+        float xa = w;                                                // xa = L^-1 w, root first (the second sweep of ldl_solve)
         const int dli = isd ? lane : 0;
-        for (int j = 0; j < nv - 1; j++) {
-          const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
-          const bool desc = isd && j < lane && lane < j + subj;
-          xa = fmaf(desc ? -HM[dli * RS + depj] : 0.f, bcast(xa, j), xa);
+        {
+          int j = 0;
+          for (; j + 8 <= nv - 1; j += 8) {
+            float l[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) l[k] = HM[dli * RS + __builtin_amdgcn_readlane(ddepth, j + k)];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+              const int subj = __builtin_amdgcn_readlane(dsub, j + k);
+              const bool desc = isd && j + k < lane && lane < j + k + subj;
+              xa = fmaf(desc ? -l[k] : 0.f, bcast(xa, j + k), xa);
+            }
+          }
+#pragma unroll 1
+          for (; j < nv - 1; j++) {
+            const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
+            const bool desc = isd && j < lane && lane < j + subj;
+            xa = fmaf(desc ? -HM[dli * RS + depj] : 0.f, bcast(xa, j), xa);
+          }
         }
         if (isd) { const float qa = xs + xa; QW[lane] = qa; if (!(fabsf(qa) <= 1e10f)) warn |= FMJ_WARN_BADQACC; }
       }
