@@ -554,7 +554,7 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
 // ---- constraint path: joint limits + plane contacts, pyramidal cone, PGS ----------
 // A row of J touches only the dofs on the chain from its body to the root: YJ[e][RS] holds it indexed by dof depth
 // and is transformed (lane = row, in registers) to Z_e = J_e L^-1 D^-1/2 (M = L'DL), so that A = J M^-1 J' = Z Z'.
-// A + diag(R) is formed explicitly (packed triangle in LDS up to LL.na rows, full rows in an HBM scratch beyond) and
+// A + diag(R) is formed explicitly (one row per lane in registers up to LL.na rows, full rows in an HBM scratch beyond) and
 // PGS runs with one row per lane.  EP[e][8] = {-, aref, R, b, force, R0, type|id bits, mu}; CH[e] = chain's last dof + 1.
 
 __device__ __forceinline__ float wave_sum_fast(float v) {   // DPP reduction, total broadcast from lane 63
