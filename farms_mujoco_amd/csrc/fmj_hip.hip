@@ -59,7 +59,7 @@ struct DevModel {
   int max_subsize;    // largest subtree (bodies)
   int rs;             // row stride of Hrow (multiple of 4, >= max dof depth + 1)
   int root_free;      // 1 if body 1 carries a free joint
-  int any_stiffness, nsensordata, njs;
+  int any_stiffness, any_box, nsensordata, njs;
   int n_links, n_joints, n_xfrc, ns;
   int anc_stride;     // bytes per chain row (multiple of 4)
   float h, gx, gy, gz, mtot_inv;
@@ -1167,7 +1167,11 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         const float4 pn = PTAB(pl, 0), pp = PTAB(pl, 1);
         for (int g0 = 0; g0 < M.ngeom; g0 += 64) {
           const int g = g0 + lane;
-          bool a0 = false, a1 = false; v3 c0 = mk3(0.f, 0.f, 0.f), c1 = c0; float d0 = 0.f, d1 = 0.f, rad = 0.f, mu = 0.f;
+          // up to 4 contacts per geom: sphere 1, capsule 2 (segment ends), box the first 4 penetrating corners in
+          // corner order (what the oracle's collide_plane does)
+          int cnt = 0; v3 cq[4]; float dq[4]; float rad = 0.f, mu = 0.f;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { cq[k] = mk3(0.f, 0.f, 0.f); dq[k] = 0.f; }
           if (g < M.ngeom) {
             const int4 gi = GTABI(g, 0);
             if (gi.x == FMJ_GEOM_SPHERE || gi.x == FMJ_GEOM_CAPSULE) {
@@ -1178,15 +1182,40 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               rad = gs.x; mu = fmaxf(pp.x, gs.w);
               v3 ax = mk3(0.f, 0.f, 0.f);
               if (gi.x == FMJ_GEOM_CAPSULE) { const q4 gqq = {gq.x, gq.y, gq.z, gq.w}; ax = scl3(qrot(qmul(bqq, gqq), mk3(0.f, 0.f, 1.f)), gs.y); }
-              c0 = add3(cen, ax); c1 = sub3(cen, ax);
-              d0 = dot3(c0, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
-              d1 = dot3(c1, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
-              a0 = d0 < 0.f; a1 = gi.x == FMJ_GEOM_CAPSULE && d1 < 0.f;
+              const v3 c0 = add3(cen, ax), c1 = sub3(cen, ax);
+              const float d0 = dot3(c0, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
+              const float d1 = dot3(c1, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
+              const bool a0 = d0 < 0.f, a1 = gi.x == FMJ_GEOM_CAPSULE && d1 < 0.f;
+              if (a0) { cq[0] = c0; dq[0] = d0; cnt = 1; }
+              if (a1) { if (cnt == 0) { cq[0] = c1; dq[0] = d1; } else { cq[1] = c1; dq[1] = d1; } cnt++; }
             }
           }
-          const unsigned long long b0 = __ballot(a0), b1 = __ballot(a1);
-          const int s0 = ncon + __popcll(b0 & lt) + __popcll(b1 & lt), s1 = s0 + (a0 ? 1 : 0);
-          ncon += __popcll(b0) + __popcll(b1);
+          if (M.any_box) {
+            const int4 gi = g < M.ngeom ? GTABI(g, 0) : make_int4(-1, 0, 0, 0);
+            if (gi.x == FMJ_GEOM_BOX) {
+              const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
+              const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+              const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
+              const q4 wq = qmul(bqq, gqq);
+              const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+              const v3 ex = scl3(qrot(wq, mk3(1.f, 0.f, 0.f)), gs.x), ey = scl3(qrot(wq, mk3(0.f, 1.f, 0.f)), gs.y), ez = scl3(qrot(wq, mk3(0.f, 0.f, 1.f)), gs.z);
+              mu = fmaxf(pp.x, gs.w);
+#pragma unroll
+              for (int corner = 0; corner < 8; corner++) {
+                const v3 c = add3(add3(cen, (corner & 1) ? ex : scl3(ex, -1.f)), add3((corner & 2) ? ey : scl3(ey, -1.f), (corner & 4) ? ez : scl3(ez, -1.f)));
+                const float d = dot3(c, mk3(pn.x, pn.y, pn.z)) - pn.w;
+                const bool pen = d < 0.f && cnt < 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (pen && cnt == k) { cq[k] = c; dq[k] = d; }
+                cnt += pen ? 1 : 0;
+              }
+            }
+          }
+          int before = 0, total = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const unsigned long long bk = __ballot(cnt > k); before += __popcll(bk & lt); total += __popcll(bk); }
+          const int s0 = ncon + before;
+          ncon += total;
           // frame: x = normal, t1 from (0,1,0) or (0,0,1) made orthogonal, t2 = n x t1 (mju_makeFrame)
           v3 nrm = mk3(pn.x, pn.y, pn.z);
           v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
@@ -1194,16 +1223,15 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
           const v3 t2 = cross(nrm, t1);
 #pragma unroll
-          for (int sgi = 0; sgi < 2; sgi++) {
-            const bool act = sgi ? a1 : a0; const int slot = sgi ? s1 : s0;
-            if (act && slot < M.max_contacts) {
-              const v3 cc = sgi ? c1 : c0; const float dd = sgi ? d1 : d0;
-              const v3 pos = sub3(cc, scl3(nrm, rad + 0.5f * dd));
+          for (int k = 0; k < 4; k++) {
+            const int slot = s0 + k;
+            if (k < cnt && slot < M.max_contacts) {
+              const v3 pos = sub3(cq[k], scl3(nrm, rad + 0.5f * dq[k]));
               float* ct = CT + slot * 16;
               *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
               *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
               *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
-              *(float4*)(ct + 12) = make_float4(dd, mu, __int_as_float(g), pp.z);
+              *(float4*)(ct + 12) = make_float4(dq[k], mu, __int_as_float(g), pp.z);
             }
           }
         }
@@ -1890,13 +1918,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
   const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
   if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
-  int any_limit = 0, nplane = 0;
+  int any_limit = 0, nplane = 0, any_box = 0;
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE) any_limit = 1;
   for (int g = 0; g < m->ngeom; g++) {
     int t = m->geom_type[g];
     if (t == FMJ_GEOM_PLANE) { if (m->geom_bodyid[g] != 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: planes must be attached to the world body"); nplane++; }
-    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule geoms are in the HIP path");
+    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule / box geoms are in the HIP path");
     else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
+    if (t == FMJ_GEOM_BOX) any_box = 1;
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane);
   if (cons && m->ngeom > nplane && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
@@ -2007,7 +2036,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       }
     }
   }
-  D.any_stiffness = any_k;
+  D.any_stiffness = any_k; D.any_box = any_box;
   D.n_links = nb - 1; D.n_joints = njs; D.n_xfrc = nb - 1; D.ns = 0;
   // actuators sorted by dof
   std::vector<float4> a_prm, a_lim; std::vector<int> a_src;

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..io.sdf import ModelSDF, Link
-from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, DEFAULT_SOLREF,
+from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, DEFAULT_SOLREF,
                      DEFAULT_SOLIMP)
 from ..units import SimulationUnitScaling
 
@@ -136,9 +136,11 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                     b.add_geom(link.name, GEOM_SPHERE, (g.size[0]*units.meters,), **gkw)
                 elif g.kind == 'capsule':
                     b.add_geom(link.name, GEOM_CAPSULE, (g.size[0]*units.meters, 0.5*g.size[1]*units.meters), **gkw)
+                elif g.kind == 'box':                   # SDF box size = full edge lengths, MuJoCo box size = half extents
+                    b.add_geom(link.name, GEOM_BOX, tuple(0.5*x*units.meters for x in g.size[:3]), **gkw)
                 else:
                     raise NotImplementedError(f'collision shape {g.kind!r} of link {link.name} is outside the HIP subset '
-                                              '(sphere / capsule against planes)')
+                                              '(sphere / capsule / box against planes)')
         for child in sdf.get_children(link):
             add_link(child, link, link.name, sdf.get_parent_joint(child))
 

@@ -285,3 +285,60 @@ def test_full_size_config4_properties(oracle):
     half = run(N//2, N//2)
     assert np.array_equal(half.physics.data.qpos.cpu().numpy(), q[N//2:])
     assert np.array_equal(half.task.data.sensors.contacts.array.cpu().numpy(), rows[:, N//2:])
+
+
+def _box_walker():
+    """A free box trunk with two hinged box limbs above a plane: plane-box contacts (up to 4 corners per geom)."""
+    from farms_mujoco_amd.model import ModelBuilder, GEOM_BOX, GEOM_PLANE
+    b = ModelBuilder('boxbot', timestep=1e-3)
+    b.options['max_contacts'] = 16
+    b.add_body('trunk', pos=(0, 0, 0.06), mass=0.5, inertia=(2e-4, 6e-4, 7e-4), joint='free')
+    b.add_geom('trunk', GEOM_BOX, (0.06, 0.03, 0.015), friction=(0.8, 0, 0))
+    for side, y in (('L', 0.04), ('R', -0.04)):
+        b.add_body(f'limb_{side}', parent='trunk', pos=(0.03, y, 0.0), mass=0.05, inertia=(2e-6, 8e-6, 8e-6),
+                   joint='hinge', axis=(0, 1, 0), damping=1e-3, limited=True, range=(-0.6, 0.6))
+        b.add_geom(f'limb_{side}', GEOM_BOX, (0.03, 0.008, 0.008), pos=(0.03, 0, -0.02), quat=(0.9659258, 0, 0.258819, 0),
+                   friction=(1.0, 0, 0))
+        b.add_position_actuator(f'joint_limb_{side}', kp=0.05)
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))
+    return b.compile()
+
+
+def test_plane_box_contacts(oracle):
+    """Box geoms against the plane (the box part): contact lists, forces and the state after a drop
+    match the oracle's corner test."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _box_walker()
+    n, T = 8, 60
+    rng = np.random.default_rng(11)
+    qpos = np.tile(m.qpos0, (n, 1))
+    qpos[:, 2] = 0.02 + 0.01*rng.uniform(size=n)                      # trunk partly below its rest height: corners touch
+    ang = 0.2*rng.normal(size=(n, 3)); qpos[:, 3] = 1.0; qpos[:, 4:7] = 0.5*ang
+    qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
+    qpos[:, 7:] = rng.uniform(-0.3, 0.3, (n, m.nq - 7))
+    qvel = 0.05*rng.normal(size=(n, m.nv))
+    phys = BatchedPhysics(m, n)
+    q32, v32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref) and ncon_ref.max() >= 4
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+    for k, tol in (('xpos', 2e-6), ('qvel', 2e-3), ('qpos', 1e-5)):
+        assert _relerr(getattr(d, k).cpu().numpy(), ref[k]) < tol, (k, _relerr(getattr(d, k).cpu().numpy(), ref[k]))
+    for e in range(n):
+        fd = fds[e]
+        got = d.contact.cpu().numpy()[e, :fd['ncon']]
+        assert np.allclose(got[:, :3], fd['contact'][:fd['ncon'], :3], atol=1e-6)
+        f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4)
+        assert np.allclose(got[:, 12], f.sum(1), rtol=2e-2, atol=2e-4)
+    # a short drop: the box comes to rest on the plane in both implementations
+    phys.step(T - 1)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=T)
+    assert int(d.status.abs().sum()) == 0
+    assert np.abs(d.qpos.cpu().numpy()[:, :3] - ref['qpos'][:, :3]).max() < 2e-3

@@ -154,3 +154,16 @@ def test_collision_subset(sdf_path):
     assert m.ngeom == 3 and m.max_contacts == 32                     # capsule + sphere + plane
     g = [i for i in range(m.ngeom) if m.geom_bodyid[i] == m.body_id('head')][0]
     assert np.allclose(m.geom_size[g][:2], [0.02, 0.05])             # capsule: radius, HALF length
+
+
+def test_box_collision_maps_to_half_extents(tmp_path, sdf_path):
+    """SDF <box><size> holds full edge lengths; the compiled geom holds MuJoCo half extents (mjcf.py:486-503)."""
+    from farms_mujoco_amd.model import GEOM_BOX
+    text = open(sdf_path).read().replace(
+        '<geometry><sphere><radius>0.02</radius></sphere></geometry>', '<geometry><box><size>0.1 0.04 0.02</size></box></geometry>')
+    p = tmp_path/'box.sdf'
+    p.write_text(text)
+    ao = _options(str(p))
+    m = sdf2model(ModelSDF.read(str(p))[0], animat_options=ao, use_collisions=True, plane=True)
+    g = [i for i in range(m.ngeom) if m.geom_type[i] == GEOM_BOX]
+    assert len(g) == 1 and np.allclose(m.geom_size[g[0]], [0.05, 0.02, 0.01])
