@@ -73,6 +73,7 @@ struct DevModel {
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
   float* cons_rows;           // [n_envs][maxefc][8] row parameters of envs with more rows than LDS holds
   float* cons_a;              // [n_envs][maxefc][AG_LD] their PGS matrix
+  float* cons_z;              // [n_envs][maxefc][rs] their compact constraint rows
   const int8_t* lcad;         // [nv][nv] depth of the deepest dof the chains of two dofs share (-1: none), padded to 4 bytes
   // ---- constraint path (joint limits, plane contacts, pyramidal cone, PGS) ----
   int cons;                   // 1 if the model has limits or collision geoms
@@ -369,32 +370,29 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
   L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.SD = L.PO = L.AT = L.LC = L.CH = o; L.na = 0;
   const int dead = 2 * nmax * 8 + r4(nb * 12);   // T/F, V/BUF, CI: not live between the M phase and the next step
-  int atx = 0;
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
     L.CT = o; o += maxcon * 16;       // contacts: pos(3) normal(3) t1(3) t2(3) dist mu geom plane
-    L.XS = o; o += r4(nv);            // qacc_smooth
-    L.WW = o; o += r4(nv);            // (spare)
+    L.XS = o; L.WW = o; o += r4(nv);  // qacc_smooth
     L.QW = o; o += r4(nv);            // qacc_warmstart
     L.DI = o; o += r4(nv);            // 1/D of the M factor
     L.SD = o; o += r4(nv);            // 1/sqrt(D)
     L.PO = o; o += nb * 8;            // body poses: xpos(3) -, xquat(4)
     L.LC = o; o += r4((nv * nv + 3) / 4);        // int8 [nv][nv]: depth of the deepest dof two chains share (-1: none)
     L.CH = o; o += r4((maxefc + 3) / 4);         // uint8 per row: last dof of the row's chain + 1
-    // Rows.  Up to na rows ("small") everything is on chip: YJ = na compact rows, EP = their parameters, A in
-    // registers (one row per lane).  With more rows the row vectors alone take YJ, EP, AT and the dead T/F, V/BUF, CI
-    // (cdof is still read while they are written); parameters and A live in HBM.
-    L.na = maxefc < FMJ_NA ? maxefc : FMJ_NA;
-    L.YJ = o; o += L.na * rs;
-    L.EP = o; o += L.na * 8;
-    const int big = r4(maxefc * rs) - (L.na * rs + L.na * 8 + dead);      // floats the spilled rows need beyond YJ, EP, dead
-    atx = r4(big > 0 ? big : 0);
-    L.AT = o; o += atx;
+    L.na = maxefc < FMJ_NA ? maxefc : FMJ_NA;    // rows kept on chip ("small"); larger row sets live in HBM, staged through YJ
+    L.EP = o; o += L.na * 8;                      // per row: -, aref, R, b, force, R0, type|id, mu
   }
+  L.CD = o; o += nv * 8;              // cdof
   L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
   L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
   L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
-  L.CD = o; o += nv * 8;              // cdof
+  if (cons) {
+    // the compact constraint rows (na x rs) overlay T/F, V/BUF and CI, which are dead from the Jacobian rows on
+    L.YJ = L.P1;
+    const int extra = L.na * rs - dead;
+    L.AT = o; if (extra > 0) o += r4(extra);
+  }
   o = r4(o);
   L.total = o;
   return L;
@@ -1243,15 +1241,15 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (4) Jacobian rows, stored compactly: a row touches only the dofs on the chain from its body to the root, so
       //     YC[e][dd] is the entry at the chain's dof of depth dd (RS floats per row) and CHN[e] names the chain's last
       //     dof (+1).  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
-      //     Up to LL.na rows everything stays in LDS ("small"); with more rows the row vectors spill over the regions
-      //     that are dead here (EP, AT, T/F, V/BUF, CI), the per-row parameters go to a global scratch and so does A.
+      //     Up to LL.na rows everything stays on chip ("small": the rows overlay T/F, V/BUF and CI, dead by now); with
+      //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
       const bool small = nefc <= LL.na;
-      float* YC = YJ;
+      float* YC = small ? YJ : M.cons_z + (size_t)env * M.maxefc * RS;
       float* EP = small ? EPL : M.cons_rows + (size_t)env * M.maxefc * 8;
       uint8_t* CHN = (uint8_t*)CH;
 #define RSYNC() do { if (!small) __threadfence(); WSYNC(); } while (0)
       for (int i = lane; i < nefc * RS; i += 64) YC[i] = 0.f;
-      WSYNC();
+      RSYNC();
       if (act_lo) { YC[e_lo * RS + ddepth] = 1.f;  CHN[e_lo] = (uint8_t)(lane + 1); float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
       if (act_hi) { YC[e_hi * RS + ddepth] = -1.f; CHN[e_hi] = (uint8_t)(lane + 1); float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
       {
@@ -1470,36 +1468,42 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         float* AG = M.cons_a + (size_t)env * M.maxefc * AG_LD;
         const int ns = (nefc + 63) >> 6;
         const int8_t* LCB = (const int8_t*)LC;
-        for (int sl = 0; sl < ns; sl++) {
-          const int e = 64 * sl + lane;
-          const bool isr = e < nefc;
-          const int chain = isr ? (int)CHN[e] - 1 : -1;
-          const float Rj = isr ? EP[e * 8 + 2] : 0.f;
-          float zr[MAXD], zm[MAXD];
-          {
-            const float* yr = YC + (isr ? e : 0) * RS;
+        for (int c0 = 0; c0 < nefc; c0 += LL.na) {       // columns c0 .. c0 + nc - 1: their rows of Z are staged in LDS
+          const int nc = nefc - c0 < LL.na ? nefc - c0 : LL.na;
+          WSYNC();
+          for (int i = lane; i < nc * RS; i += 64) YJ[i] = YC[c0 * RS + i];
+          WSYNC();
+          for (int sl = 0; sl < ns; sl++) {
+            const int e = 64 * sl + lane;
+            const bool isr = e < nefc;
+            const int chain = isr ? (int)CHN[e] - 1 : -1;
+            const float Rj = isr ? EP[e * 8 + 2] : 0.f;
+            float zr[MAXD], zm[MAXD];
+            {
+              const float* yr = YC + (isr ? e : 0) * RS;
 #pragma unroll
-            for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
-          }
-#pragma unroll
-          for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
-          int cprev = -2;
-          for (int f = 0; f < nefc; f++) {
-            const int cf = (int)CHN[f] - 1;
-            if (cf != cprev) {
-              cprev = cf;
-              const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
-#pragma unroll
-              for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
+              for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
             }
-            const float* yf = YC + f * RS;
-            float a0 = 0.f;
 #pragma unroll
-            for (int g4 = 0; g4 < MAXD / 4; g4++) {
-              const float4 v = *(const float4*)(yf + 4 * g4);
-              a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
+            for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
+            int cprev = -2;
+            for (int f = 0; f < nc; f++) {
+              const int cf = (int)CHN[c0 + f] - 1;
+              if (cf != cprev) {
+                cprev = cf;
+                const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
+#pragma unroll
+                for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
+              }
+              const float* yf = YJ + f * RS;
+              float a0 = 0.f;
+#pragma unroll
+              for (int g4 = 0; g4 < MAXD / 4; g4++) {
+                const float4 v = *(const float4*)(yf + 4 * g4);
+                a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
+              }
+              AG[(size_t)(c0 + f) * AG_LD + 64 * sl + lane] = a0 + (c0 + f == e ? Rj : 0.f);
             }
-            AG[(size_t)f * AG_LD + 64 * sl + lane] = a0 + (f == e ? Rj : 0.f);
           }
         }
         __threadfence();
@@ -2231,17 +2235,20 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
   c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
   for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
-  D.cons_rows = nullptr; D.cons_a = nullptr;
+  D.cons_rows = nullptr; D.cons_a = nullptr; D.cons_z = nullptr;
   if (D.cons && D.maxefc > 0) {   // HBM scratch of envs whose constraint rows outgrow LDS (fmj_step_kernel<.., CONS = true>, "big" path)
     void* p1 = nullptr; void* p2 = nullptr;
+    void* p3 = nullptr;
     if (hipMalloc(&p1, (size_t)n_envs * D.maxefc * 8 * sizeof(float)) != hipSuccess ||
-        hipMalloc(&p2, (size_t)n_envs * D.maxefc * AG_LD * sizeof(float)) != hipSuccess) {
-      if (p1) hipFree(p1);
+        hipMalloc(&p2, (size_t)n_envs * D.maxefc * AG_LD * sizeof(float)) != hipSuccess ||
+        hipMalloc(&p3, (size_t)n_envs * D.maxefc * D.rs * sizeof(float)) != hipSuccess) {
+      if (p1) (void)hipFree(p1);
+      if (p2) (void)hipFree(p2);
       fmj_destroy(c);
       return set_err(FMJ_ERR_HIP, "fmj_create: out of device memory for the constraint scratch");
     }
-    c->allocs.push_back(p1); c->allocs.push_back(p2);
-    D.cons_rows = (float*)p1; D.cons_a = (float*)p2;
+    c->allocs.push_back(p1); c->allocs.push_back(p2); c->allocs.push_back(p3);
+    D.cons_rows = (float*)p1; D.cons_a = (float*)p2; D.cons_z = (float*)p3;
   }
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
   c->lds_bytes = (size_t)L.total * sizeof(float);
