@@ -183,6 +183,16 @@ __device__ __forceinline__ q4 axisangle(v3 ax, float ang) {
   q4 r = {c, ax.x * s, ax.y * s, ax.z * s};
   return r;
 }
+// the free joint turns by h*|omega| per step: for half-angles below 0.25 rad the Taylor polynomials are exact to
+// fp32 (sin: x^9/9! < 1e-11, cos: x^10/10! < 3e-13) and cost a tenth of the range-reduced sincosf
+__device__ __forceinline__ q4 axisangle_small(v3 ax, float ang) {
+  const float x = 0.5f * ang, x2 = x * x;
+  if (!(fabsf(x) <= 0.25f)) return axisangle(ax, ang);
+  const float s = x * fmaf(x2, fmaf(x2, fmaf(x2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+  const float c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+  q4 r = {c, ax.x * s, ax.y * s, ax.z * s};
+  return r;
+}
 struct m33 { float a[9]; };
 __device__ __forceinline__ m33 q2m(q4 q) {
   m33 m;
@@ -1702,7 +1712,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       const float n = sqrtf(dot3(w, w));
       q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
       qo = qnormalize(qo);
-      if (n >= 1e-15f) qo = qmul(qo, axisangle(scl3(w, 1.0f / n), M.h * n));
+      if (n >= 1e-15f) qo = qmul(qo, axisangle_small(scl3(w, 1.0f / n), M.h * n));
       QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
       if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
     }
