@@ -87,6 +87,8 @@ struct DevModel {
   int dual_nround;
   const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
   int nround1;
+  const uint32_t* dual_ancl;           // [32][rs / 4] per lane dof: 4 * (lane of its ancestor at each absolute depth), own lane elsewhere
+  int dual_maxdep;                     // deepest absolute depth of a lane dof
 };
 
 
@@ -2238,6 +2240,21 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       D.dual_nround = (int)rounds.size();
       if (rounds.empty()) { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; rounds.push_back(R); }
       UP(rounds, dual_rounds);
+      {   // per lane dof, per absolute depth: byte = 4 * lane of the ancestor at that depth (the solve pulls x from there
+          // with ds_bpermute); own lane where there is none.  The kernel adds the half's offset.
+        std::vector<uint32_t> ancl((size_t)32 * (D.rs / 4), 0u);
+        int md = 0;
+        for (int i = 0; i < 32; i++) {
+          uint8_t* row = (uint8_t*)&ancl[(size_t)i * (D.rs / 4)];
+          for (int l = 0; l < D.rs; l++) row[l] = (uint8_t)(4 * i);
+          if (D.dual_ok && i < nd) {
+            if (ddepth[i + t0] > md) md = ddepth[i + t0];
+            for (int a = m->dof_parentid[i + t0]; a >= t0; a = m->dof_parentid[a]) row[ddepth[a]] = (uint8_t)(4 * (a - t0));
+          }
+        }
+        D.dual_maxdep = md;
+        UP(ancl, dual_ancl);
+      }
     }
   }
   c->d_btab = (float4*)D.btab; c->d_dtab = (float4*)D.dtab;
