@@ -1542,49 +1542,39 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           const int mode = pass < 0 ? 0 : 1;
           imp = 0.f;
 
-          float cur[PB][3], nxt[PB][3];
-#pragma unroll
-          for (int r = 0; r < PB; r++) {
-            const int e = r < nefc ? r : nefc - 1;
-#pragma unroll
-            for (int sl = 0; sl < 3; sl++) cur[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f;
+          // rows in order, one slot (64 rows, one per lane) after the other so that the slot is static in the row code;
+          // rows of A are fetched one block of PB rows ahead
+#define PGS_SLOT(S_) \
+          if (S_ < ns) { \
+            const int ebeg = 64 * S_, eend = nefc < 64 * S_ + 64 ? nefc : 64 * S_ + 64; \
+            float cur[PB][3], nxt[PB][3]; \
+            _Pragma("unroll") for (int r = 0; r < PB; r++) { \
+              const int e = ebeg + r < eend ? ebeg + r : eend - 1; \
+              _Pragma("unroll") for (int sl = 0; sl < 3; sl++) cur[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f; \
+            } \
+            for (int e0 = ebeg; e0 < eend; e0 += PB) { \
+              _Pragma("unroll") for (int r = 0; r < PB; r++) { \
+                const int e = e0 + PB + r < eend ? e0 + PB + r : eend - 1; \
+                _Pragma("unroll") for (int sl = 0; sl < 3; sl++) nxt[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f; \
+              } \
+              _Pragma("unroll") for (int r = 0; r < PB; r++) { \
+                const int e = e0 + r; \
+                if (e < eend) { \
+                  float dj, t = 0.f; \
+                  if (mode == 0) dj = fw[S_]; \
+                  else { dj = fmaxf(nf[S_], res[S_] * nainv[S_]); t = fmaf(hdiag[S_], dj, res[S_]); }   /* no revert: see (8a) */ \
+                  const float delta = bcast(dj, e & 63); \
+                  _Pragma("unroll") for (int sl = 0; sl < 3; sl++) res[sl] = fmaf(cur[r][sl], delta, res[sl]); \
+                  const float md = lane == (e & 63) ? dj : 0.f; \
+                  nf[S_] -= md; imp = fmaf(md, t, imp); \
+                } \
+              } \
+              _Pragma("unroll") for (int r = 0; r < PB; r++) \
+                _Pragma("unroll") for (int sl = 0; sl < 3; sl++) cur[r][sl] = nxt[r][sl]; \
+            } \
           }
-          for (int e0 = 0; e0 < nefc; e0 += PB) {
-#pragma unroll
-            for (int r = 0; r < PB; r++) {
-              const int e = e0 + PB + r < nefc ? e0 + PB + r : nefc - 1;
-#pragma unroll
-              for (int sl = 0; sl < 3; sl++) nxt[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < PB; r++) {
-              const int e = e0 + r;
-              if (e < nefc) {
-                const int se = e >> 6, le = e & 63;
-                float dj, t = 0.f;
-                if (mode == 0) dj = se == 0 ? fw[0] : (se == 1 ? fw[1] : fw[2]);
-                else {
-                  const float rs_ = se == 0 ? res[0] : (se == 1 ? res[1] : res[2]);
-                  const float nf_ = se == 0 ? nf[0] : (se == 1 ? nf[1] : nf[2]);
-                  const float na_ = se == 0 ? nainv[0] : (se == 1 ? nainv[1] : nainv[2]);
-                  const float hd_ = se == 0 ? hdiag[0] : (se == 1 ? hdiag[1] : hdiag[2]);
-                  const float cand = fmaxf(nf_, rs_ * na_);
-                  t = fmaf(hd_, cand, rs_);
-                  dj = cand;                                   // the revert of mj_solPGS cannot fire for scalar rows, see (8a)
-                }
-                const float delta = bcast(dj, le);
-#pragma unroll
-                for (int sl = 0; sl < 3; sl++) res[sl] = fmaf(cur[r][sl], delta, res[sl]);
-                const float md = lane == le ? dj : 0.f;
-                if (se == 0) nf[0] -= md; else if (se == 1) nf[1] -= md; else nf[2] -= md;
-                imp = fmaf(md, t, imp);
-              }
-            }
-#pragma unroll
-            for (int r = 0; r < PB; r++)
-#pragma unroll
-              for (int sl = 0; sl < 3; sl++) cur[r][sl] = nxt[r][sl];
-          }
+          PGS_SLOT(0) PGS_SLOT(1) PGS_SLOT(2)
+#undef PGS_SLOT
           if (mode == 0) {   // dual cost of the warm start; start from f = 0 if that is better
             float cost = 0.f;
 #pragma unroll
