@@ -53,10 +53,14 @@ def random_tree(seed):
     return b.compile()
 
 
-@pytest.mark.parametrize('seed', range(14))
-def test_random_tree_vs_oracle(oracle, seed):
+@pytest.mark.parametrize('seed,two_per_wave', [(s, True) for s in range(20)] + [(s, False) for s in range(0, 20, 2)])
+def test_random_tree_vs_oracle(oracle, seed, two_per_wave, monkeypatch):
+    """Every tree here has <= 32 bodies, so it runs in the two-envs-per-wave kernel by default; FMJ_DUAL=0 (read at
+    fmj_create) sends the same tree through the one-env-per-wave kernel."""
     import torch
     from farms_mujoco_amd.physics import BatchedPhysics
+    if not two_per_wave:
+        monkeypatch.setenv('FMJ_DUAL', '0')
     m = random_tree(seed)
     if m is None or m.nv == 0:
         pytest.skip('degenerate draw')
@@ -71,6 +75,7 @@ def test_random_tree_vs_oracle(oracle, seed):
     xf = rng.normal(size=(n, m.nbody, 6))*0.05; xf[:, 0] = 0
     qs = np.tile(m.qpos_spring, (n, 1)) + rng.uniform(-0.1, 0.1, (n, m.nq))
     phys = BatchedPhysics(m, n)
+    assert phys.kernel_info()['threads_per_env'] == (32 if two_per_wave else 64)
     d = phys.data
     f32 = lambda a: torch.as_tensor(a, dtype=torch.float32)
     d.qpos[:] = f32(qpos); d.qvel[:] = f32(qvel); d.xfrc_applied[:] = f32(xf); d.qpos_spring[:] = f32(qs)
