@@ -7,8 +7,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def random_tree(seed):
-    from farms_mujoco_amd.model import ModelBuilder, euler2quat
+def random_tree(seed, contacts=False):
+    from farms_mujoco_amd.model import ModelBuilder, euler2quat, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_PLANE
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(3, 22))
     free = bool(rng.integers(0, 2))
@@ -38,8 +38,22 @@ def random_tree(seed):
                 jkw = dict(joint=jt, axis=rng.normal(size=3), jpos=rng.normal(size=3)*0.03 if rng.random() < 0.5 else (0, 0, 0),
                            damping=float(rng.choice([0.0, 2e-3, 1e-2])), stiffness=float(rng.choice([0.0, 0.0, 0.05])),
                            armature=float(rng.choice([0.0, 1e-4])), qpos0=float(rng.choice([0.0, 0.2])))
+                if contacts and jt == 'hinge' and rng.random() < 0.5:
+                    jkw.update(limited=True, range=(-0.3, 0.25))
             b.add_body(name, parent, pos=rng.normal(size=3)*0.08, quat=euler2quat(rng.normal(size=3)*0.5), **jkw, **kw)
         names.append(name)
+        if contacts and rng.random() < 0.7:
+            kind = int(rng.integers(0, 3))
+            gk = dict(pos=rng.normal(size=3)*0.02, quat=euler2quat(rng.normal(size=3)), friction=(float(rng.uniform(0.3, 1.0)), 0, 0))
+            if kind == 0:
+                b.add_geom(name, GEOM_SPHERE, (float(rng.uniform(0.02, 0.05)),), **gk)
+            elif kind == 1:
+                b.add_geom(name, GEOM_CAPSULE, (float(rng.uniform(0.015, 0.03)), float(rng.uniform(0.02, 0.06))), **gk)
+            else:
+                b.add_geom(name, GEOM_BOX, tuple(rng.uniform(0.015, 0.05, 3)), **gk)
+    if contacts:
+        b.add_geom('world', GEOM_PLANE, (0, 0, 0), pos=(0, 0, -0.05), friction=(0.2, 0, 0))
+        b.options['max_contacts'] = 32
     joints = [bd.joint['name'] for bd in b.bodies[1:] if bd.joint and bd.joint['type'] != 0]
     for jn in joints:
         r = rng.random()
@@ -97,3 +111,51 @@ def test_random_tree_vs_oracle(oracle, seed, two_per_wave, monkeypatch):
     torch.cuda.synchronize()
     ref = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None, qpos_spring=s32, xfrc_applied=x32, n_steps=50)
     assert err('qpos') < 2e-3, (seed, 'qpos50', err('qpos'))
+
+
+@pytest.mark.parametrize('seed', range(100, 112))
+def test_random_tree_with_limits_and_contacts(oracle, seed):
+    """The constraint path on random trees: limited hinges, sphere / capsule / box geoms over a plane that cuts
+    through the tree; contact lists, constraint forces and the state after one and after 30 steps vs the oracle."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = random_tree(seed, contacts=True)
+    if m is None or m.nv == 0:
+        pytest.skip('degenerate draw')
+    rng = np.random.default_rng(2000 + seed)
+    n = 6
+    qpos = np.tile(m.qpos0, (n, 1)) + rng.uniform(-0.4, 0.4, (n, m.nq))
+    for j in range(m.njnt):
+        if m.jnt_type[j] == 0:
+            a = m.jnt_qposadr[j]; q = rng.normal(size=(n, 4)); qpos[:, a+3:a+7] = q/np.linalg.norm(q, axis=1, keepdims=True)
+            qpos[:, a+2] = rng.uniform(-0.05, 0.1, n)
+    qvel = rng.normal(size=(n, m.nv))*0.2
+    ctrl = rng.uniform(-0.4, 0.4, (n, max(m.nu, 1)))[:, :m.nu]
+    phys = BatchedPhysics(m, n)
+    assert phys.kernel_info()['threads_per_env'] == 64
+    d = phys.data
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32)
+    d.qpos[:] = f32(qpos); d.qvel[:] = f32(qvel)
+    if m.nu:
+        d.ctrl[:] = f32(ctrl)
+    r64 = lambda t: t.cpu().numpy().astype(np.float64)
+    q32, v32, c32 = r64(d.qpos), r64(d.qvel), r64(d.ctrl)
+    phys.step(1)
+    torch.cuda.synchronize()
+    assert int((d.status & ~4).abs().sum()) == 0                       # CONTACTFULL (bit 4) may be raised by both sides
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=c32[e] if m.nu else None) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref), (d.ncon.cpu().numpy(), ncon_ref)
+    ref = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None)
+
+    def err(k):
+        a = r64(getattr(d, k)); bb = ref[k]
+        return np.abs(a - bb).max()/max(np.abs(bb).max(), 1e-9)
+    for k, tol in (('xpos', 5e-6), ('qvel', 3e-3), ('qpos', 2e-5)):
+        assert err(k) < tol, (seed, m.nbody, m.nv, ncon_ref, k, err(k))
+    for e in range(n):
+        fd = fds[e]
+        if fd['ncon']:
+            f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4).sum(1)
+            got = d.contact.cpu().numpy()[e, :fd['ncon'], 12]
+            assert np.allclose(got, f, rtol=3e-2, atol=2e-3*max(1.0, np.abs(f).max())), (seed, e, got, f)
