@@ -97,8 +97,8 @@ _lib = None
 def build(force: bool = False, verbose: bool = False) -> str:
     """Compile csrc/fmj_hip.hip for gfx950 into csrc/libfmj_hip.so (hipcc cross-compiles without a GPU)."""
     src = os.path.join(CSRC, 'fmj_hip.hip')
-    stale = (not os.path.exists(SO_PATH) or os.path.getmtime(SO_PATH) < os.path.getmtime(src)
-             or os.path.getmtime(SO_PATH) < os.path.getmtime(HEADER))
+    deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.inc')]
+    stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(SO_PATH) < os.path.getmtime(d) for d in deps)
     if force or stale:
         cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC', '-shared', src, '-o', SO_PATH]
         if verbose:

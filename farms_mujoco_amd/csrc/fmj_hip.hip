@@ -1255,420 +1255,17 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       //     dof (+1).  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
       //     Up to LL.na rows everything stays on chip ("small": the rows overlay T/F, V/BUF and CI, dead by now); with
       //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
-      const bool small = nefc <= LL.na;
-      float* YC = small ? YJ : M.cons_z + (size_t)env * M.maxefc * RS;
-      float* EP = small ? EPL : M.cons_rows + (size_t)env * M.maxefc * 8;
-      uint8_t* CHN = (uint8_t*)CH;
-#define RSYNC() do { if (!small) __threadfence(); WSYNC(); } while (0)
-      for (int i = lane; i < nefc * RS; i += 64) YC[i] = 0.f;
-      RSYNC();
-      if (act_lo) { YC[e_lo * RS + ddepth] = 1.f;  CHN[e_lo] = (uint8_t)(lane + 1); float* ep = EP + e_lo * 8; ep[0] = dist_lo; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
-      if (act_hi) { YC[e_hi * RS + ddepth] = -1.f; CHN[e_hi] = (uint8_t)(lane + 1); float* ep = EP + e_hi * 8; ep[0] = dist_hi; ep[1] = lim.w; ep[6] = __int_as_float(lane); ep[7] = 0.f; }
-      {
-        const s6 cd = isd ? lds_get6(CD + lane * 8) : s6{mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)};
-        for (int c = 0; c < ncon; c++) {
-          const float* ct = CT + c * 16;
-          const float4 c0 = *(const float4*)(ct), c1 = *(const float4*)(ct + 4), c2 = *(const float4*)(ct + 8), c3 = *(const float4*)(ct + 12);
-          const int g = __float_as_int(c3.z);
-          const int last = GTABI(g, 0).z;                       // last dof on the contact body's chain
-          const bool on = isd && last >= 0 && lane <= last && last < lane + dsub;
-          if (on) {
-            const v3 jp = add3(cd.l, cross(cd.r, sub3(mk3(c0.x, c0.y, c0.z), com)));
-            const float jn = dot3(jp, mk3(c0.w, c1.x, c1.y));
-            const float j1 = c3.y * dot3(jp, mk3(c1.z, c1.w, c2.x));
-            const float j2 = c3.y * dot3(jp, mk3(c2.y, c2.z, c2.w));
-            float* y = YC + (nlim + 4 * c) * RS + ddepth;
-            y[0] = jn + j1; y[RS] = jn - j1; y[2 * RS] = jn + j2; y[3 * RS] = jn - j2;
-          }
-          if (lane < 4) { CHN[nlim + 4 * c + lane] = (uint8_t)(last + 1); float* ep = EP + (nlim + 4 * c + lane) * 8; ep[0] = c3.x; ep[1] = 0.f; ep[6] = __int_as_float(0x40000000 | c); ep[7] = c3.y; }
-        }
-      }
-      RSYNC();
-      STAMP(14);  // J rows
-      // (5) per row (lane = row, 64 rows per pass): R, aref (mj_makeImpedance / mj_referenceConstraint),
-      //     b = J qacc_smooth - aref, warm-start jar from the previous qacc (mj_fwdConstraint), then
-      // (6) Z = J L^-1 D^-1/2 with the row in registers: walking the chain from its last dof i to the root,
-      //     y[dd2] -= L[i][dd2] y[depth(i)] for dd2 < depth(i); A = J M^-1 J' = Z Z'.
-      for (int e0 = 0; e0 < nefc; e0 += 64) {
-        const int e = e0 + lane;
-        const bool isr = e < nefc;
-        float* ep = EP + (isr ? e : 0) * 8;
-        const int tid = __float_as_int(ep[6]);
-        const bool is_con = (tid & 0x40000000) != 0;
-        const int chain = isr ? (int)CHN[e] - 1 : -1;
-        float sr0, sr1, si0, si1, si2, si3, si4, dapx;
-        const float mu = ep[7];
-        if (is_con) {
-          const float4 c3 = *(const float4*)(CT + (tid & 0xff) * 16 + 12);
-          const int g = __float_as_int(c3.z);
-          const float4 a = GTAB(g, 4), b = GTAB(g, 5);
-          sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z;
-          const float tran = GTAB(g, 2).w;                       // invweight0 of the body (+ 0 for the world plane)
-          dapx = tran + mu * mu * tran;
-        } else {
-          const float4 a = DTAB(tid & 0xff, 4), b = DTAB(tid & 0xff, 5);
-          sr0 = a.x; sr1 = a.y; si0 = a.z; si1 = a.w; si2 = b.x; si3 = b.y; si4 = b.z; dapx = b.w;
-        }
-        float R, kimp, bb;
-        row_params(sr0, sr1, si0, si1, si2, si3, si4, ep[0], ep[1], dapx, h, &R, &kimp, &bb);
-        float y[MAXD];
-        {
-          const float* yr = YC + (isr ? e : 0) * RS;
-#pragma unroll
-          for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); y[4 * g4] = v.x; y[4 * g4 + 1] = v.y; y[4 * g4 + 2] = v.z; y[4 * g4 + 3] = v.w; }
-        }
-        const int cdep_raw = __builtin_amdgcn_ds_bpermute((chain < 0 ? 0 : chain) << 2, ddepth);   // all lanes take part: a masked-off source lane reads as 0
-        const int cdep = chain >= 0 ? cdep_raw : -1;
-        int ii[MAXD];                                             // the chain's dof at each depth (0 beyond the chain)
-        float vel = 0.f, jxs = 0.f, jqw = 0.f;
-        {
-          int i = chain < 0 ? 0 : chain;
-#pragma unroll
-          for (int dd = MAXD - 1; dd >= 0; dd--) {
-            if (dd < MAXD - 1) { const int pi = __builtin_amdgcn_ds_bpermute(i << 2, dparent); i = dd < cdep ? pi : i; }
-            ii[dd] = dd <= cdep ? i : 0;
-            const float j = y[dd];
-            vel = fmaf(j, QV[ii[dd]], vel); jxs = fmaf(j, XS[ii[dd]], jxs); jqw = fmaf(j, QW[ii[dd]], jqw);
-          }
-        }
-        const float aref = -bb * vel - kimp * (ep[0] - ep[1]);
-#pragma unroll
-        for (int dd = MAXD - 1; dd >= 1; dd--) {
-          const float yi = y[dd];
-          const float* lr = HM + ii[dd] * RS;
-#pragma unroll
-          for (int g4 = 0; g4 < (dd + 3) / 4; g4++) {
-            const float4 l4 = *(const float4*)(lr + 4 * g4);
-            if (4 * g4 + 0 < dd) y[4 * g4 + 0] = fmaf(-l4.x, yi, y[4 * g4 + 0]);
-            if (4 * g4 + 1 < dd) y[4 * g4 + 1] = fmaf(-l4.y, yi, y[4 * g4 + 1]);
-            if (4 * g4 + 2 < dd) y[4 * g4 + 2] = fmaf(-l4.z, yi, y[4 * g4 + 2]);
-            if (4 * g4 + 3 < dd) y[4 * g4 + 3] = fmaf(-l4.w, yi, y[4 * g4 + 3]);
-          }
-        }
-#pragma unroll
-        for (int dd = 0; dd < MAXD; dd++) y[dd] *= SD[ii[dd]];
-        if (isr) {
-          float* yr = YC + e * RS;
-#pragma unroll
-          for (int g4 = 0; g4 < MAXD / 4; g4++) *(float4*)(yr + 4 * g4) = make_float4(y[4 * g4], y[4 * g4 + 1], y[4 * g4 + 2], y[4 * g4 + 3]);
-          ep[1] = aref; ep[2] = R; ep[3] = jxs - aref; ep[4] = jqw - aref; ep[5] = R;   // ep[4]: jar for the warm start; ep[5]: R before the pyramidal fix
-        }
-      }
-      RSYNC();
-      // pyramidal: the 4 rows of a contact share R = 2 mu^2 R_first (mu scaled by 1/sqrt(impratio))
-      for (int e = lane; e < nefc; e += 64) {
-        float* ep = EP + e * 8;
-        const int tid = __float_as_int(ep[6]);
-        if (tid & 0x40000000) {
-          const int e0 = nlim + 4 * (tid & 0xff);
-          const float mu = ep[7] * M.impratio_isqrt;
-          ep[2] = fmaxf(1e-15f, 2.f * mu * mu * EP[e0 * 8 + 5]);
-        }
-        const float jar = ep[4]; ep[4] = jar < 0.f ? -jar / ep[2] : 0.f;        // warm-start force
-      }
-      RSYNC();
-      STAMP(16);  // row params + Z
-      float w = 0.f;
-      if (small) {
-        // (7a) explicit A = Z Z' + diag(R), lane = row: lane j keeps row j of A in FMJ_NA registers (A is symmetric, so
-        //      this is also column j).  Rows e and f share the dofs of depth <= lcad(chain_e, chain_f); the lane's row
-        //      of Z is masked once per run of columns with the same chain (the 4 rows of a contact).  The column loop
-        //      is unrolled so that every register index is static; it leaves at the first column >= nefc.
-        const bool isr = lane < nefc;
-        const int je = isr ? lane : 0;
-        const int chain = isr ? (int)CHN[je] - 1 : -1;
-        float areg[FMJ_NA];
-        {
-          const int8_t* LCB = (const int8_t*)LC;
-          const float Rj = EP[je * 8 + 2];
-          float zr[MAXD], zm[MAXD];
-          {
-            const float* yr = YC + je * RS;
-#pragma unroll
-            for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
-          }
-#pragma unroll
-          for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
-          int cprev = -2;
-#pragma unroll
-          for (int f = 0; f < FMJ_NA; f++) {
-            areg[f] = 0.f;
-            if (f < nefc) {
-              const int cf = __builtin_amdgcn_readlane(chain, f);
-              if (cf != cprev) {
-                cprev = cf;
-                const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
-#pragma unroll
-                for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
-              }
-              const float* yf = YC + f * RS;
-              float a0 = f == je ? Rj : 0.f;
-#pragma unroll
-              for (int g4 = 0; g4 < MAXD / 4; g4++) {
-                const float4 v = *(const float4*)(yf + 4 * g4);
-                a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
-              }
-              areg[f] = a0;
-            }
-          }
-        }
-        STAMP(17);  // A
-        // warm start: keep it only if its dual cost beats f = 0 (mj_fwdConstraint)
-        float fj = isr ? EP[je * 8 + 4] : 0.f;
-        const float bj = isr ? EP[je * 8 + 3] : 0.f;
-        float diag = 1.f;                                            // A_jj + R_j: the lane's own column of its row
-#pragma unroll
-        for (int f = 0; f < FMJ_NA; f++) diag = (f == lane && isr) ? areg[f] : diag;
-        const float ainv = 1.0f / diag;
-        float afj = 0.f;
-#pragma unroll
-        for (int k = 0; k < FMJ_NA; k++) if (k < nefc) afj = fmaf(areg[k], bcast(fj, k), afj);
-        {
-          const float cost = wave_sum_fast(fj * (0.5f * afj + bj));
-          if (cost > 0.f) { fj = 0.f; afj = 0.f; }
-        }
-        float res = bj + afj;                                        // residual of row j: b + (A + R) f
-        STAMP(18);  // warm start
-        // (8a) PGS on the explicit matrix (mj_solPGS: rows in order, f_e <- max(0, f_e - res_e / A_ee)).  Every lane
-        //      keeps the update its own row would make from its current residual (delta_j = max(-f_j, -res_j / A_jj));
-        //      row e's turn is then one v_readlane of that value and one FMA of every residual with the lane's
-        //      register e: no reduction, no LDS, no address arithmetic, a dependent chain of 4 VALU ops per row.
-        //      mj_solPGS reverts a row whose cost change delta * (0.5 A_ee delta + res) exceeds 1e-10; for these scalar
-        //      rows the two factors never have the same sign, in floating point too (delta = -res/A_ee gives
-        //      t = res/2; the clamped delta = -f gives t >= res/2 > 0), so the revert cannot fire and is not
-        //      evaluated; the product still feeds the improvement that stops the sweeps.
-        const float hdiag = 0.5f * diag;
-        const float nainv = -ainv;
-        float nf = -fj;
-        // Rows past nefc are no-ops by construction (their lanes hold res = 0, f = 0 and a zero row), so the sweep is
-        // straight-line code for the next multiple of 12 rows: static register indices, one branch per step.
-#define PGS_SWEEPS(NR_) \
-        for (int itp = 0; itp < M.solver_iterations; itp++) { \
-          float imp = 0.f; \
-          _Pragma("unroll") for (int e = 0; e < NR_; e++) { \
-            float cand; asm("v_max_f32_e32 %0, %1, %2" : "=v"(cand) : "v"(nf), "v"(res * nainv));   /* no NaN canonicalisation */ \
-            const float t = fmaf(hdiag, cand, res);                   /* cost change of the row = cand * t */ \
-            res = fmaf(areg[e], bcast(cand, e), res); \
-            float md; const unsigned long long bit_ = 1ull << e; \
-            asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(md) : "v"(cand), "s"(bit_)); \
-            nf -= md; imp = fmaf(md, t, imp); \
-          } \
-          const float improvement = -wave_sum_fast(imp); \
-          if (improvement * M.pgs_scale < M.solver_tolerance) break; \
-        }
-        if (nefc <= 12) { PGS_SWEEPS(12) }
-        else if (nefc <= 24) { PGS_SWEEPS(24) }
-        else if (nefc <= 36) { PGS_SWEEPS(36) }
-        else if (nefc <= 48) { PGS_SWEEPS(48) }
-        else { PGS_SWEEPS(FMJ_NA) }
-#undef PGS_SWEEPS
-        fj = -nf;
-        if (isr) EP[je * 8 + 4] = fj;
-        if (isd) {
-          for (int e = 0; e < nefc; e++) {
-            const int ce = (int)CHN[e] - 1;
-            const bool on = lane <= ce && ce < lane + dsub;
-            w = fmaf(on ? YC[e * RS + ddepth] : 0.f, bcast(fj, e), w);
-          }
-          w *= sqrtf(dinv_m);
-        }
-        WSYNC();
+      if (nefc <= LL.na) {
+        constexpr bool small = true;
+        float* const YC = YJ;
+        float* const EP = EPL;
+#include "fmj_cons_rows.inc"
       } else {
-        // (7b) more rows than the LDS matrix holds: A = Z Z' + diag(R) goes to the global scratch, full rows of
-        //      AG_LD floats (row f is written by the lanes that own rows e: A is symmetric, so the stores coalesce),
-        //      and each lane owns up to three rows (e = lane + 64 s).
-        float* AG = M.cons_a + (size_t)env * M.maxefc * AG_LD;
-        const int ns = (nefc + 63) >> 6;
-        const int8_t* LCB = (const int8_t*)LC;
-        for (int c0 = 0; c0 < nefc; c0 += LL.na) {       // columns c0 .. c0 + nc - 1: their rows of Z are staged in LDS
-          const int nc = nefc - c0 < LL.na ? nefc - c0 : LL.na;
-          WSYNC();
-          for (int i = lane; i < nc * RS; i += 64) YJ[i] = YC[c0 * RS + i];
-          WSYNC();
-          for (int sl = 0; sl < ns; sl++) {
-            const int e = 64 * sl + lane;
-            const bool isr = e < nefc;
-            const int chain = isr ? (int)CHN[e] - 1 : -1;
-            const float Rj = isr ? EP[e * 8 + 2] : 0.f;
-            float zr[MAXD], zm[MAXD];
-            {
-              const float* yr = YC + (isr ? e : 0) * RS;
-#pragma unroll
-              for (int g4 = 0; g4 < MAXD / 4; g4++) { const float4 v = *(const float4*)(yr + 4 * g4); zr[4 * g4] = v.x; zr[4 * g4 + 1] = v.y; zr[4 * g4 + 2] = v.z; zr[4 * g4 + 3] = v.w; }
-            }
-#pragma unroll
-            for (int dd = 0; dd < MAXD; dd++) zm[dd] = 0.f;
-            int cprev = -2;
-            for (int f = 0; f < nc; f++) {
-              const int cf = (int)CHN[c0 + f] - 1;
-              if (cf != cprev) {
-                cprev = cf;
-                const int l = (cf >= 0 && chain >= 0) ? (int)LCB[chain * nv + cf] : -1;
-#pragma unroll
-                for (int dd = 0; dd < MAXD; dd++) zm[dd] = dd <= l ? zr[dd] : 0.f;
-              }
-              const float* yf = YJ + f * RS;
-              float a0 = 0.f;
-#pragma unroll
-              for (int g4 = 0; g4 < MAXD / 4; g4++) {
-                const float4 v = *(const float4*)(yf + 4 * g4);
-                a0 = fmaf(zm[4 * g4], v.x, a0); a0 = fmaf(zm[4 * g4 + 1], v.y, a0); a0 = fmaf(zm[4 * g4 + 2], v.z, a0); a0 = fmaf(zm[4 * g4 + 3], v.w, a0);
-              }
-              AG[(size_t)(c0 + f) * AG_LD + 64 * sl + lane] = a0 + (c0 + f == e ? Rj : 0.f);
-            }
-          }
-        }
-        __threadfence();
-        WSYNC();
-        STAMP(17);  // A
-        // per-lane row state (slot s = row lane + 64 s)
-        float res[3], nf[3], nainv[3], hdiag[3], bj[3];
-#pragma unroll
-        for (int sl = 0; sl < 3; sl++) {
-          const int e = 64 * sl + lane;
-          const bool isr = e < nefc;
-          const float dg = isr ? AG[(size_t)e * AG_LD + e] : 1.f;
-          bj[sl] = isr ? EP[e * 8 + 3] : 0.f;
-          res[sl] = bj[sl]; nf[sl] = 0.f; nainv[sl] = -1.0f / dg; hdiag[sl] = 0.5f * dg;
-        }
-        // one pass over the rows: mode 0 applies the warm-start forces as given deltas (builds res = b + (A + R) f),
-        // mode 1 is a PGS sweep.  Rows of A are fetched PB rows ahead of their use.
-        constexpr int PB = 8;
-        float imp = 0.f;
-        float fw[3];
-#pragma unroll
-        for (int sl = 0; sl < 3; sl++) { const int e = 64 * sl + lane; fw[sl] = e < nefc ? EP[e * 8 + 4] : 0.f; }
-        for (int pass = -1; pass < M.solver_iterations; pass++) {
-          const int mode = pass < 0 ? 0 : 1;
-          imp = 0.f;
-
-          // rows in order, one slot (64 rows, one per lane) after the other so that the slot is static in the row code;
-          // rows of A are fetched one block of PB rows ahead
-#define PGS_SLOT(S_) \
-          if (S_ < ns) { \
-            const int ebeg = 64 * S_, eend = nefc < 64 * S_ + 64 ? nefc : 64 * S_ + 64; \
-            float cur[PB][3], nxt[PB][3]; \
-            _Pragma("unroll") for (int r = 0; r < PB; r++) { \
-              const int e = ebeg + r < eend ? ebeg + r : eend - 1; \
-              _Pragma("unroll") for (int sl = 0; sl < 3; sl++) cur[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f; \
-            } \
-            for (int e0 = ebeg; e0 < eend; e0 += PB) { \
-              _Pragma("unroll") for (int r = 0; r < PB; r++) { \
-                const int e = e0 + PB + r < eend ? e0 + PB + r : eend - 1; \
-                _Pragma("unroll") for (int sl = 0; sl < 3; sl++) nxt[r][sl] = sl < ns ? AG[(size_t)e * AG_LD + 64 * sl + lane] : 0.f; \
-              } \
-              _Pragma("unroll") for (int r = 0; r < PB; r++) { \
-                const int e = e0 + r; \
-                if (e < eend) { \
-                  float dj, t = 0.f; \
-                  if (mode == 0) dj = fw[S_]; \
-                  else { dj = fmaxf(nf[S_], res[S_] * nainv[S_]); t = fmaf(hdiag[S_], dj, res[S_]); }   /* no revert: see (8a) */ \
-                  const float delta = bcast(dj, e & 63); \
-                  _Pragma("unroll") for (int sl = 0; sl < 3; sl++) res[sl] = fmaf(cur[r][sl], delta, res[sl]); \
-                  const float md = lane == (e & 63) ? dj : 0.f; \
-                  nf[S_] -= md; imp = fmaf(md, t, imp); \
-                } \
-              } \
-              _Pragma("unroll") for (int r = 0; r < PB; r++) \
-                _Pragma("unroll") for (int sl = 0; sl < 3; sl++) cur[r][sl] = nxt[r][sl]; \
-            } \
-          }
-          PGS_SLOT(0) PGS_SLOT(1) PGS_SLOT(2)
-#undef PGS_SLOT
-          if (mode == 0) {   // dual cost of the warm start; start from f = 0 if that is better
-            float cost = 0.f;
-#pragma unroll
-            for (int sl = 0; sl < 3; sl++) cost += (-nf[sl]) * (0.5f * (res[sl] - bj[sl]) + bj[sl]);
-            cost = wave_sum_fast(cost);
-            if (cost > 0.f) {
-#pragma unroll
-              for (int sl = 0; sl < 3; sl++) { nf[sl] = 0.f; res[sl] = bj[sl]; }
-            }
-          } else {
-            const float improvement = -wave_sum_fast(imp);
-            if (improvement * M.pgs_scale < M.solver_tolerance) break;
-          }
-        }
-#pragma unroll
-        for (int sl = 0; sl < 3; sl++) { const int e = 64 * sl + lane; if (e < nefc) EP[e * 8 + 4] = -nf[sl]; }
-        __threadfence();
-        WSYNC();
-        if (isd) {
-          for (int e = 0; e < nefc; e++) {
-            const int ce = (int)CHN[e] - 1;
-            const bool on = lane <= ce && ce < lane + dsub;
-            w = fmaf(on ? YC[e * RS + ddepth] : 0.f, EP[e * 8 + 4], w);
-          }
-          w *= sqrtf(dinv_m);
-        }
-        WSYNC();
+        constexpr bool small = false;
+        float* const YC = M.cons_z + (size_t)env * M.maxefc * RS;
+        float* const EP = M.cons_rows + (size_t)env * M.maxefc * 8;
+#include "fmj_cons_rows.inc"
       }
-      STAMP(19);  // PGS
-      // (9) qfrc_constraint = J' f = L'(Y' f) ; qacc = qacc_smooth + L^-1 w  (saved as next step's warm start)
-      {
-        const float u = isd ? w / dinv_m : 0.f;                      // (Y' f)_d
-        float q = u;                                                 // q_a = u_a + sum over descendants i of L[i][a] u_i: no chain, LDS reads batched
-        {
-          int i = nv - 1;
-          for (; i >= 8; i -= 8) {
-            float l[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) l[k] = HM[(i - k) * RS + ddepth];
-#pragma unroll
-            for (int k = 0; k < 8; k++) { const bool anc = lane < i - k && i - k < lane + dsub; q = fmaf(anc ? l[k] : 0.f, bcast(u, i - k), q); }
-          }
-#pragma unroll 1
-          for (; i >= 1; i--) { const bool anc = lane < i && i < lane + dsub; q = fmaf(anc ? HM[i * RS + ddepth] : 0.f, bcast(u, i), q); }
-        }
-        qfrc_c = q;
-        float xa = w;                                                // xa = L^-1 w, root first (the second sweep of ldl_solve)
-        const int dli = isd ? lane : 0;
-        {
-          int j = 0;
-          for (; j + 8 <= nv - 1; j += 8) {
-            float l[8];
-#pragma unroll
-            for (int k = 0; k < 8; k++) l[k] = HM[dli * RS + __builtin_amdgcn_readlane(ddepth, j + k)];
-#pragma unroll
-            for (int k = 0; k < 8; k++) {
-              const int subj = __builtin_amdgcn_readlane(dsub, j + k);
-              const bool desc = isd && j + k < lane && lane < j + k + subj;
-              xa = fmaf(desc ? -l[k] : 0.f, bcast(xa, j + k), xa);
-            }
-          }
-#pragma unroll 1
-          for (; j < nv - 1; j++) {
-            const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
-            const bool desc = isd && j < lane && lane < j + subj;
-            xa = fmaf(desc ? -HM[dli * RS + depj] : 0.f, bcast(xa, j), xa);
-          }
-        }
-        if (isd) { const float qa = xs + xa; QW[lane] = qa; if (!(fabsf(qa) <= 1e10f)) warn |= FMJ_WARN_BADQACC; }
-      }
-      STAMP(20);  // qfrc_constraint + warm start
-      // (10) sensors: joint limit force; contact forces in the contact frame (mj_contactForce, pyramidal)
-      {
-        float lf = 0.f;
-        if (act_lo) lf += EP[e_lo * 8 + 4];
-        if (act_hi) lf += EP[e_hi * 8 + 4];
-        cy_limfrc = lf * A.inv_torques;
-        cy_ncon = ncon;
-        WSYNC();
-        for (int c = lane; c < ncon; c += 64) {                   // complete the LDS records: force(3) + geom2 id
-          const float* ep = EP + (nlim + 4 * c) * 8;
-          const float f0 = ep[4], f1 = ep[12], f2 = ep[20], f3 = ep[28], mu = ep[7];
-          float* ct = CT + c * 16;
-          const float g2 = ct[14];
-          ct[12] = f0 + f1 + f2 + f3; ct[13] = mu * (f0 - f1); ct[14] = mu * (f2 - f3); ct[15] = g2;
-        }
-        WSYNC();
-        if (last && d_scalar) A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z + 2] = lf;
-        if (last) {
-          for (int i = lane; i < ncon * 16; i += 64) A.contact[(size_t)env * M.max_contacts * 16 + i] = CT[i];
-          if (lane == 0) A.ncon[env] = ncon;
-        }
-      }
-      WSYNC();
     }
     // ---- L + X: sparse L'DL of H = M + diag(armature + h*damping) and the solve H qacc = qfrc_smooth
     float my_qacc;
