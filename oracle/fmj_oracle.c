@@ -26,6 +26,10 @@
 #include <string.h>
 #include <pthread.h>
 
+/* diagnostics: sweeps the last PGS solve ran (single-threaded use only) */
+static int g_last_pgs_iterations = 0;
+int fmjo_last_pgs_iterations(void) { return g_last_pgs_iterations; }
+
 #include "../include/fmj.h"
 
 #define MINVAL 1e-15
@@ -665,6 +669,7 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
       w->efc_force[i] = f;
       improvement -= change;
     }
+    g_last_pgs_iterations = it + 1;
     if (improvement * scale < m->solver_tolerance) break;
   }
   for (int e = 0; e < n; e++) {
