@@ -127,10 +127,11 @@ typedef struct fmj_model {
   const int32_t* actuator_forcelimited;
   const double* actuator_forcerange; /* [nu,2] (task.py:279-286 rewrites this at run time) */
 
-  /* collision geoms [ngeom] (config 4: animat geoms vs plane) */
-  const int32_t* geom_type;
+  /* collision geoms [ngeom] (config 4: animat geoms vs plane; reference mjcf.py:251-527).  Supported pairs: plane
+   * (world-attached) against sphere (1 contact), capsule (2: segment ends) and box (first 4 penetrating corners). */
+  const int32_t* geom_type;     /* FMJ_GEOM_* */
   const int32_t* geom_bodyid;
-  const double* geom_size;      /* [ngeom,3] */
+  const double* geom_size;      /* [ngeom,3] MuJoCo sizes: sphere r; capsule r, half length; box half extents */
   const double* geom_pos;       /* [ngeom,3] body frame */
   const double* geom_quat;      /* [ngeom,4] */
   const double* geom_friction;  /* [ngeom,3] */
