@@ -94,17 +94,37 @@ SYMBOLS = {
 _lib = None
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """Compile csrc/fmj_hip.hip for gfx950 into csrc/libfmj_hip.so (hipcc cross-compiles without a GPU)."""
+def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
+    """Compile csrc/fmj_hip.hip for gfx950 into csrc/libfmj_hip.so (hipcc cross-compiles without a GPU).
+    ``defines`` / ``out`` build a variant next to it (scripts/stamps.py: ``-DFMJ_STAMPS``)."""
     src = os.path.join(CSRC, 'fmj_hip.hip')
+    target = SO_PATH if out is None else os.path.join(CSRC, out)
     deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.inc')]
-    stale = not os.path.exists(SO_PATH) or any(os.path.getmtime(SO_PATH) < os.path.getmtime(d) for d in deps)
+    stale = not os.path.exists(target) or any(os.path.getmtime(target) < os.path.getmtime(d) for d in deps)
     if force or stale:
-        cmd = ['hipcc', '--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC', '-shared', src, '-o', SO_PATH]
-        if verbose:
-            cmd.insert(1, '-Rpass-analysis=kernel-resource-usage')
-        subprocess.check_call(cmd)
-    return SO_PATH
+        # one object per register row length (the step-kernel instantiations) + one for the host side, compiled in
+        # parallel, then linked: the single translation unit took 2.3 min, this takes the time of the slowest object
+        import concurrent.futures
+        import tempfile
+        flags = ['--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC'] + list(defines)
+        with tempfile.TemporaryDirectory(prefix='fmj_build_') as tmp:
+            jobs = [(os.path.join(tmp, 'host.o'), [])] + [(os.path.join(tmp, f'k{n}.o'), [f'-DFMJ_TU_MAXD={n}'])
+                                                          for n in range(4, 33, 4)]
+
+            def cc(job):
+                obj, defs = job
+                cmd = ['hipcc'] + flags + defs + ['-c', src, '-o', obj]
+                if verbose:
+                    print(' '.join(cmd))
+                subprocess.check_call(cmd)
+                return obj
+            with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+                objs = list(ex.map(cc, jobs))
+            cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', target]
+            if verbose:
+                print(' '.join(cmd))
+            subprocess.check_call(cmd)
+    return target
 
 
 def load():

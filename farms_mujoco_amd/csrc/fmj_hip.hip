@@ -1334,6 +1334,20 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #include "fmj_dual.inc"
 
 // ---------------------------------------------------------------------------------------------
+// Build layout: this file is compiled once per register row length with -DFMJ_TU_MAXD=<4..32> (only the step-kernel
+// instantiations of that MAXD and a getter for their host stubs) and once without it (standalone operators and all
+// host code), in parallel, and the objects are linked into one libfmj_hip.so (farms_mujoco_amd/_lib.py).
+#ifdef FMJ_TU_MAXD
+#define FMJ_CAT2(a, b) a##b
+#define FMJ_CAT(a, b) FMJ_CAT2(a, b)
+extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
+  if (dual) return fused ? (void*)fmj_step_dual_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual_kernel<false, FMJ_TU_MAXD>;
+  if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
+  return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
+}
+#else
+
+// ---------------------------------------------------------------------------------------------
 // standalone operators (same arithmetic as the fused loop; one wave per env)
 
 // SwimmingHandler.step (reference drag.pyx:389-411): lane = swimming link
@@ -1436,36 +1450,27 @@ static float ibits(int i) { float f; memcpy(&f, &i, 4); return f; }
 
 // pick the instantiation whose register row length matches the model's dof-chain length
 typedef void (*step_kernel_t)(const DevModel, const StepArgs);
-template <bool FUSED, bool CONS>
-static step_kernel_t pick_step_kernel(int rs) {
+extern "C" {
+void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
+void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
+}
+static step_kernel_t tu_kernel(int rs, bool fused, bool cons, bool dual) {
+  void* k;
   switch (rs) {
-    case 4: return fmj_step_kernel<FUSED, 4, CONS>;
-    case 8: return fmj_step_kernel<FUSED, 8, CONS>;
-    case 12: return fmj_step_kernel<FUSED, 12, CONS>;
-    case 16: return fmj_step_kernel<FUSED, 16, CONS>;
-    case 20: return fmj_step_kernel<FUSED, 20, CONS>;
-    case 24: return fmj_step_kernel<FUSED, 24, CONS>;
-    case 28: return fmj_step_kernel<FUSED, 28, CONS>;
-    default: return fmj_step_kernel<FUSED, 32, CONS>;
+    case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
+    case 8: k = fmj_tu_kernel_8(fused, cons, dual); break;
+    case 12: k = fmj_tu_kernel_12(fused, cons, dual); break;
+    case 16: k = fmj_tu_kernel_16(fused, cons, dual); break;
+    case 20: k = fmj_tu_kernel_20(fused, cons, dual); break;
+    case 24: k = fmj_tu_kernel_24(fused, cons, dual); break;
+    case 28: k = fmj_tu_kernel_28(fused, cons, dual); break;
+    default: k = fmj_tu_kernel_32(fused, cons, dual); break;
   }
+  return (step_kernel_t)k;
 }
-static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  if (c->dm.cons) return fused ? pick_step_kernel<true, true>(c->dm.rs) : pick_step_kernel<false, true>(c->dm.rs);
-  return fused ? pick_step_kernel<true, false>(c->dm.rs) : pick_step_kernel<false, false>(c->dm.rs);
-}
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons != 0, false); }
 template <bool FUSED>
-static step_kernel_t pick_dual_kernel(int rs) {
-  switch (rs) {
-    case 4: return fmj_step_dual_kernel<FUSED, 4>;
-    case 8: return fmj_step_dual_kernel<FUSED, 8>;
-    case 12: return fmj_step_dual_kernel<FUSED, 12>;
-    case 16: return fmj_step_dual_kernel<FUSED, 16>;
-    case 20: return fmj_step_dual_kernel<FUSED, 20>;
-    case 24: return fmj_step_dual_kernel<FUSED, 24>;
-    case 28: return fmj_step_dual_kernel<FUSED, 28>;
-    default: return fmj_step_dual_kernel<FUSED, 32>;
-  }
-}
+static step_kernel_t pick_dual_kernel(int rs) { return tu_kernel(rs, FUSED, false, true); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual.inc); fmj_forward keeps the single-env kernel
     step_kernel_t k = fused ? pick_dual_kernel<true>(c->dm.rs) : pick_dual_kernel<false>(c->dm.rs);
@@ -2181,3 +2186,4 @@ int fmj_sc(const char* name) {
 }
 
 }  // extern "C"
+#endif  // FMJ_TU_MAXD

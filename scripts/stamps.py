@@ -1,4 +1,5 @@
-"""Diagnostic: per-phase cycle shares of the fused step kernel (build with -DFMJ_STAMPS)."""
+"""Diagnostic: per-phase cycle shares of the fused step kernel (a -DFMJ_STAMPS build of the library, made on demand:
+``python -c "from farms_mujoco_amd import _lib; _lib.build(defines=['-DFMJ_STAMPS'], out='libfmj_hip_stamps.so')"``)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from farms_mujoco_amd import _lib
