@@ -68,3 +68,40 @@ def test_mixed_batch_bucketed(oracle):
         assert int(sim.physics.data.status.abs().sum()) == 0
         links = sim.task.data.sensors.links.array.cpu().numpy()
         assert np.isfinite(links).all() and np.abs(links[-1, :, :, 14:17]).max() > 1e-3      # it swims
+
+
+@pytest.mark.parametrize('n_envs', [1, 3])
+def test_longest_chain_two_per_wave(oracle, n_envs):
+    """Edge of the two-envs-per-wave kernel: a fixed-base chain of 31 hinges (nbody 32, nv 31, dof depth 31: the
+    MAXD = 32 instantiation, every lane of a half in use) with 1 and 3 envs (a wave whose upper half is idle)."""
+    import torch
+    from farms_mujoco_amd.model import ModelBuilder
+    from farms_mujoco_amd.physics import BatchedPhysics
+    b = ModelBuilder('chain31', timestep=1e-3)
+    rng = np.random.default_rng(7)
+    parent = 'world'
+    for i in range(31):
+        ax = [(0, 0, 1), (0, 1, 0), (1, 0, 0)][i % 3]
+        b.add_body(f'l{i}', parent, pos=(0.03, 0, 0) if i else (0, 0, 0.5), mass=0.02, ipos=(0.015, 0, 0),
+                   inertia=(2e-6, 4e-6, 4e-6), joint='hinge', axis=ax, damping=2e-4, stiffness=0.01 if i % 4 == 0 else 0.0)
+        b.add_position_actuator(f'joint_l{i}', kp=0.02)
+        parent = f'l{i}'
+    m = b.compile()
+    assert m.nbody == 32 and m.nv == 31
+    phys = BatchedPhysics(m, n_envs)
+    assert phys.kernel_info()['threads_per_env'] == 32
+    d = phys.data
+    qpos = rng.uniform(-0.3, 0.3, (n_envs, m.nq)); qvel = rng.normal(size=(n_envs, m.nv))*0.3
+    ctrl = rng.uniform(-0.3, 0.3, (n_envs, m.nu))
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    d.ctrl[:] = torch.as_tensor(ctrl, dtype=torch.float32)
+    r64 = lambda t: t.cpu().numpy().astype(np.float64)
+    q32, v32, c32, s32 = r64(d.qpos), r64(d.qvel), r64(d.ctrl), r64(d.qpos_spring)
+    phys.step(30)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=c32, qpos_spring=s32, n_steps=30)
+    assert int(d.status.abs().sum()) == 0
+    # a 31-link whip is badly conditioned in fp32 (mass matrix condition number ~1e6): looser than the animal models
+    for k, tol in (('qpos', 3e-4), ('qvel', 5e-3), ('xpos', 3e-4)):
+        e = np.abs(r64(getattr(d, k)) - ref[k]).max()/max(np.abs(ref[k]).max(), 1e-9)
+        assert e < tol, (k, e)
