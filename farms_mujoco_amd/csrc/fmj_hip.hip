@@ -87,6 +87,8 @@ struct DevModel {
   int dual_nround;
   const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
   int nround1;
+  const uint32_t* ancl1;               // [64][rs / 4] the same table for the one-env kernel (lane = dof)
+  int maxdep1;                         // deepest dof depth
   const uint32_t* dual_ancl;           // [32][rs / 4] per lane dof: 4 * (lane of its ancestor at each absolute depth), own lane elsewhere
   int dual_maxdep;                     // deepest absolute depth of a lane dof
 };
@@ -515,7 +517,8 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
 
 // x = (L' D L)^-1 rhs with v_readlane broadcasts; HR rows hold L (see ldl_factor), dinv = 1/D_lane.
 template <int MAXD>
-__device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane, bool isd, int ddepth, int dsub, int nv, float dinv_mine) {
+__device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane, bool isd, int ddepth, int dsub, int nv, float dinv_mine,
+                                           const uint32_t* ancl, int maxdep) {
   constexpr int RS = MAXD;
   float x = rhs;
   const int dli = isd ? lane : 0;                 // in-bounds row for idle lanes; their result is discarded
@@ -538,24 +541,23 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
     }
   }
   x *= dinv_mine;
-  {
-    int j = 0;
-    for (; j + 8 <= nv - 1; j += 8) {
-      float l[8];
+  {   // root first, a tree level at a time: every lane pulls x of its ancestor at depth lvl with one ds_bpermute (lane
+      // table from the model) and applies its own L entry for that depth (its row, read once up front)
+    float4 row[MAXD / 4];
 #pragma unroll
-      for (int u = 0; u < 8; u++) l[u] = HR[dli * RS + __builtin_amdgcn_readlane(ddepth, j + u)];
+    for (int g = 0; g < MAXD / 4; g++) row[g] = *(const float4*)(HR + dli * RS + 4 * g);
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int subj = __builtin_amdgcn_readlane(dsub, j + u);
-        const bool desc = isd && j + u < lane && lane < j + u + subj;
-        x = fmaf(desc ? -l[u] : 0.f, bcast(x, j + u), x);
+    for (int g = 0; g < MAXD / 4; g++) {
+      const uint32_t ab = ancl[(unsigned)dli * (MAXD / 4) + g];
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int lvl = 4 * g + k;
+        if (lvl < maxdep) {
+          const float xs = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((ab >> (8 * k)) & 0xffu), __float_as_int(x)));
+          const float rl = k == 0 ? row[g].x : (k == 1 ? row[g].y : (k == 2 ? row[g].z : row[g].w));
+          x = fmaf((isd && lvl < ddepth) ? -rl : 0.f, xs, x);
+        }
       }
-    }
-#pragma unroll 1
-    for (; j < nv - 1; j++) {
-      const int depj = __builtin_amdgcn_readlane(ddepth, j), subj = __builtin_amdgcn_readlane(dsub, j);
-      const float l = (isd && j < lane && lane < j + subj) ? HR[lane * RS + depj] : 0.f;
-      x = fmaf(-l, bcast(x, j), x);
     }
   }
   return x;
@@ -1155,7 +1157,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       {
         ldl_factor<MAXD>(HM, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_m);
       }
-      const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m);
+      const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m, M.ancl1, M.maxdep1);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); }
       STAMP(12);  // factor M + qacc_smooth
       // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
@@ -1273,7 +1275,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       float dinv_mine;
       ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_mine);
       STAMP(9);   // L
-      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine);
+      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine, M.ancl1, M.maxdep1);
     }
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
@@ -1800,6 +1802,16 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       }
       D.nround1 = (int)rounds.size();
       UP(rounds, rounds1);
+      {   // per dof, per depth: byte = 4 * lane of the ancestor at that depth (own lane where there is none)
+        std::vector<uint32_t> ancl((size_t)64 * (D.rs / 4), 0u);
+        for (int i = 0; i < 64; i++) {
+          uint8_t* row = (uint8_t*)&ancl[(size_t)i * (D.rs / 4)];
+          for (int l = 0; l < D.rs; l++) row[l] = (uint8_t)(4 * i);
+          if (i < nv) for (int a = m->dof_parentid[i]; a >= 0; a = m->dof_parentid[a]) row[ddepth[a]] = (uint8_t)(4 * a);
+        }
+        D.maxdep1 = maxdep;
+        UP(ancl, ancl1);
+      }
     }
     {   // elimination rounds: lane dofs grouped by depth, deepest first, at most three per round
       const int nd = nv - t0 > 0 ? nv - t0 : 0;
