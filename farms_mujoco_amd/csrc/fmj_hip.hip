@@ -515,7 +515,32 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
   WSYNC();
 }
 
-// x = (L' D L)^-1 rhs with v_readlane broadcasts; HR rows hold L (see ldl_factor), dinv = 1/D_lane.
+// Root-first sweep x_d -= L[d][a] x_a over the proper ancestors a of d, a tree level at a time: every lane pulls x of
+// its ancestor at depth lvl with one ds_bpermute (lane table from the model: byte = 4 * lane) and applies its own L
+// entry for that depth (its row of HR, read once up front).  maxdep dependent steps instead of one per dof.
+template <int MAXD>
+__device__ __forceinline__ float ldl_pull_sweep(const float* HR, float x, int dli, bool isd, int ddepth, const uint32_t* ancl, int maxdep) {
+  constexpr int RS = MAXD;
+  float4 row[MAXD / 4];
+#pragma unroll
+  for (int g = 0; g < MAXD / 4; g++) row[g] = *(const float4*)(HR + dli * RS + 4 * g);
+#pragma unroll
+  for (int g = 0; g < MAXD / 4; g++) {
+    const uint32_t ab = ancl[(unsigned)dli * (MAXD / 4) + g];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int lvl = 4 * g + k;
+      if (lvl < maxdep) {
+        const float xs = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((ab >> (8 * k)) & 0xffu), __float_as_int(x)));
+        const float rl = k == 0 ? row[g].x : (k == 1 ? row[g].y : (k == 2 ? row[g].z : row[g].w));
+        x = fmaf((isd && lvl < ddepth) ? -rl : 0.f, xs, x);
+      }
+    }
+  }
+  return x;
+}
+
+// x = (L' D L)^-1 rhs; HR rows hold L (see ldl_factor), dinv = 1/D_lane.
 template <int MAXD>
 __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane, bool isd, int ddepth, int dsub, int nv, float dinv_mine,
                                            const uint32_t* ancl, int maxdep) {
@@ -541,25 +566,7 @@ __device__ __forceinline__ float ldl_solve(const float* HR, float rhs, int lane,
     }
   }
   x *= dinv_mine;
-  {   // root first, a tree level at a time: every lane pulls x of its ancestor at depth lvl with one ds_bpermute (lane
-      // table from the model) and applies its own L entry for that depth (its row, read once up front)
-    float4 row[MAXD / 4];
-#pragma unroll
-    for (int g = 0; g < MAXD / 4; g++) row[g] = *(const float4*)(HR + dli * RS + 4 * g);
-#pragma unroll
-    for (int g = 0; g < MAXD / 4; g++) {
-      const uint32_t ab = ancl[(unsigned)dli * (MAXD / 4) + g];
-#pragma unroll
-      for (int k = 0; k < 4; k++) {
-        const int lvl = 4 * g + k;
-        if (lvl < maxdep) {
-          const float xs = __int_as_float(__builtin_amdgcn_ds_bpermute((int)((ab >> (8 * k)) & 0xffu), __float_as_int(x)));
-          const float rl = k == 0 ? row[g].x : (k == 1 ? row[g].y : (k == 2 ? row[g].z : row[g].w));
-          x = fmaf((isd && lvl < ddepth) ? -rl : 0.f, xs, x);
-        }
-      }
-    }
-  }
+  x = ldl_pull_sweep<MAXD>(HR, x, dli, isd, ddepth, ancl, maxdep);
   return x;
 }
 
