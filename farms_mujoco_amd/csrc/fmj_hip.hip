@@ -447,6 +447,8 @@ __device__ __forceinline__ double subtree_sum_f64(double x, int last) {
 // tracked in its own register so D_k comes from a v_readlane before the LDS round trip.  Slots past a lane's
 // depth only ever hold finite garbage that is never read as a matrix entry (the caller zero-fills HR before
 // assembling the matrix).  On return HR holds the final rows (L*D) and dinv = 1/D_lane.
+// 1/x to fp32 accuracy: hardware reciprocal (1 ulp) refined by one Newton step
+__device__ __forceinline__ float rcp_nr(float x) { const float r = __builtin_amdgcn_rcpf(x); return r * (2.0f - x * r); }
 // v where the lane's bit in the (uniform) mask is set, else 0
 __device__ __forceinline__ float mask_select(const float v, const unsigned long long m) {
   float r;
