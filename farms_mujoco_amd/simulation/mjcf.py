@@ -184,3 +184,74 @@ def setup_model(simulation_options, animat_options, arena_options=None, **kwargs
     return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options,
                      fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane, plane=plane,
                      **{k: v for k, v in mujoco_kw.items() if k in ('solref', 'solimp', 'friction')}, **kwargs)
+
+
+def model2mjcf_xml(m: Model) -> str:
+    """The compiled model as an MJCF document (what ``Simulation.save_mjcf_xml`` writes in the reference,
+    simulation.py:215-225 via ``mjcf.export_with_assets``): compiler / option blocks as mjcf.py:1244-1403 sets them,
+    the body tree with explicit inertials, joints, collision geoms, the actuator triple and the sensors of
+    mjcf.py:950-1002.  The text loads in MuJoCo; nothing in this package reads it back."""
+    import xml.etree.ElementTree as ET
+    from ..model import JNT_FREE, JNT_SLIDE, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX
+
+    def v(a):
+        return ' '.join(repr(float(x)) for x in np.asarray(a).ravel())
+    root = ET.Element('mujoco', model=str(getattr(m, 'name', 'animat')))
+    ET.SubElement(root, 'compiler', angle='radian', eulerseq='xyz', inertiafromgeom='false', balanceinertia='false',
+                  boundmass='0', boundinertia='0', fusestatic='true')
+    ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone='pyramidal',
+                  solver='PGS', iterations=str(int(m.solver_iterations)), tolerance=repr(float(m.solver_tolerance)),
+                  impratio=repr(float(m.impratio)))
+    ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))
+    world = ET.SubElement(root, 'worldbody')
+    elems = {0: world}
+    gtypes = {GEOM_PLANE: 'plane', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_BOX: 'box'}
+    for b in range(1, m.nbody):
+        e = ET.SubElement(elems[int(m.body_parentid[b])], 'body', name=m.body_names[b], pos=v(m.body_pos[b]), quat=v(m.body_quat[b]))
+        elems[b] = e
+        ET.SubElement(e, 'inertial', pos=v(m.body_ipos[b]), quat=v(m.body_iquat[b]), mass=repr(float(m.body_mass[b])),
+                      diaginertia=v(m.body_inertia[b]))
+        j = int(m.body_jntadr[b])
+        if j >= 0:
+            if m.jnt_type[j] == JNT_FREE:
+                ET.SubElement(e, 'freejoint', name=m.joint_names[j])
+            else:
+                d = int(m.jnt_dofadr[j])
+                at = dict(name=m.joint_names[j], type='slide' if m.jnt_type[j] == JNT_SLIDE else 'hinge', pos=v(m.jnt_pos[j]),
+                          axis=v(m.jnt_axis[j]), stiffness=repr(float(m.jnt_stiffness[j])), damping=repr(float(m.dof_damping[d])),
+                          armature=repr(float(m.dof_armature[d])), ref=repr(float(m.qpos0[m.jnt_qposadr[j]])),
+                          springref=repr(float(m.qpos_spring[m.jnt_qposadr[j]])))
+                if m.jnt_limited[j]:
+                    at.update(limited='true', range=v(m.jnt_range[j]), margin=repr(float(m.jnt_margin[j])),
+                              solreflimit=v(m.jnt_solref[j]), solimplimit=v(m.jnt_solimp[j]))
+                ET.SubElement(e, 'joint', **at)
+    for g in range(m.ngeom):
+        t = int(m.geom_type[g])
+        size = {GEOM_PLANE: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
+        ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]),
+                      friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]), solimp=v(m.geom_solimp[g]), condim='3', margin='0')
+    if m.nu:
+        act = ET.SubElement(root, 'actuator')
+        for a in range(m.nu):
+            at = dict(name=m.actuator_names[a], joint=m.joint_names[int(m.actuator_jntid[a])], gainprm=repr(float(m.actuator_gain[a])),
+                      biasprm=v(m.actuator_bias[a]), biastype='affine')
+            if m.actuator_ctrllimited[a]:
+                at.update(ctrllimited='true', ctrlrange=v(m.actuator_ctrlrange[a]))
+            if m.actuator_forcelimited[a]:
+                at.update(forcelimited='true', forcerange=v(m.actuator_forcerange[a]))
+            ET.SubElement(act, 'general', **at)
+    sens = ET.SubElement(root, 'sensor')
+    for b in range(1, m.nbody):
+        ET.SubElement(sens, 'framelinvel', name=f'framelinvel_{m.body_names[b]}', objtype='body', objname=m.body_names[b])
+        ET.SubElement(sens, 'frameangvel', name=f'frameangvel_{m.body_names[b]}', objtype='body', objname=m.body_names[b])
+    for j in range(m.njnt):
+        if m.jnt_type[j] != JNT_FREE:
+            for kind in ('jointpos', 'jointvel', 'jointlimitfrc'):
+                ET.SubElement(sens, kind, name=f'{kind}_{m.joint_names[j]}', joint=m.joint_names[j])
+    for a in range(m.nu):
+        ET.SubElement(sens, 'actuatorfrc', name=f'actuatorfrc_{m.actuator_tags[a]}_{m.joint_names[int(m.actuator_jntid[a])]}',
+                      actuator=m.actuator_names[a])
+    key = ET.SubElement(root, 'keyframe')
+    ET.SubElement(key, 'key', name='initial', qpos=v(m.key_qpos), qvel=v(getattr(m, 'key_qvel', np.zeros(m.nv))))
+    ET.indent(root) if hasattr(ET, 'indent') else None
+    return ET.tostring(root, encoding='unicode')

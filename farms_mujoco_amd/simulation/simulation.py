@@ -172,4 +172,11 @@ class Simulation:
                 self.task.animat_options.save(os.path.join(log_path, 'animat_options.yaml'))
 
     def save_mjcf_xml(self, path: str, verbose: bool = False):
-        raise NotImplementedError('MJCF export belongs to the model-compiler row (SURVEY §8 f1)')
+        """Save the compiled model as MJCF XML (reference simulation.py:215-225)."""
+        from .mjcf import model2mjcf_xml
+        xml = model2mjcf_xml(self.physics.model)
+        with open(path, 'w') as f:
+            f.write(xml)
+        if verbose:
+            pylog.info(xml)
+        return path
