@@ -57,7 +57,9 @@ class Simulation:
         """From SDF (reference simulation.py:96-124): compiles ``animat_options.sdf`` with
         :func:`~farms_mujoco_amd.simulation.mjcf.setup_model`, or takes a pre-built ``model=``."""
         model = kwargs.pop('model', None)
-        extract_sub_dict(kwargs, ('spawn_position', 'spawn_rotation', 'save_mjcf', 'use_particles'))
+        save_mjcf = kwargs.pop('save_mjcf', False)
+        show_mjcf = kwargs.pop('show_mjcf', False)
+        extract_sub_dict(kwargs, ('spawn_position', 'spawn_rotation', 'use_particles'))
         if model is None:       # setup_mjcf_xml role (reference simulation.py:105-116)
             from .mjcf import setup_model
             model = setup_model(simulation_options, animat_options, arena_options)
@@ -66,6 +68,14 @@ class Simulation:
         if water is not None and water.height is not None and (water.drag or water.sph) \
                 and not any(isinstance(cb, SwimmingCallback) for cb in callbacks):
             callbacks = [SwimmingCallback(animat_options, arena_options)] + list(callbacks)
+        if save_mjcf or show_mjcf:                   # reference mjcf.py:1503-1509
+            from .mjcf import model2mjcf_xml
+            xml = model2mjcf_xml(model)
+            if show_mjcf:
+                pylog.info(xml)
+            if save_mjcf:
+                with open(save_mjcf if isinstance(save_mjcf, str) else 'simulation_mjcf.xml', 'w+', encoding='utf-8') as f:
+                    f.write(xml)
         return cls(mjcf_model=model, base_link=model.body_names[1], simulation_options=simulation_options,
                    animat_options=animat_options, callbacks=callbacks, **kwargs)
 
