@@ -104,3 +104,24 @@ def test_long_horizon_swim_parity(oracle):
     err = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max()/np.abs(ref['qpos']).max()
     print('qpos rel err after 4000 steps:', err)
     assert err < 1e-4, err
+
+
+def test_twenty_seconds_of_swimming_stay_sane():
+    """20 000 fused steps (20 s of simulated swimming, ring of 100 rows wrapping 200 times) on 1024 envs: no warning
+    bit, everything finite, joints inside a sane range, the animals keep moving, the ring holds the last 100 rows."""
+    import torch
+    import bench
+    sim, m, _ = bench.build_sim(1024, 20000, 100, 0, 'cuda:0', 'swim')
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    q = d.qpos.cpu().numpy(); v = d.qvel.cpu().numpy()
+    assert np.isfinite(q).all() and np.isfinite(v).all()
+    assert np.abs(q[:, 7:]).max() < 1.5 and np.abs(v).max() < 50.0
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1.0).max() < 1e-5
+    links = sim.task.data.sensors.links.array.cpu().numpy()
+    assert np.isfinite(links).all()
+    speed = np.linalg.norm(links[:, :, 0, 14:17], axis=-1)              # head link CoM speed over the last 100 steps
+    assert 0.005 < speed.mean() < 2.0
+    assert sim.task.iteration == 20000
