@@ -721,9 +721,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const uint8_t* JMP = (const uint8_t*)(lds + LL.ANC);   // [nb][anc_stride]: ancestor at distance 2^r
   float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
   float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EPL = lds + LL.EP;  float* CT = lds + LL.CT;
-  float* XS = lds + LL.XS;  float* WW = lds + LL.WW;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
-  float* PO = lds + LL.PO;  float* AT = lds + LL.AT;  float* LC = lds + LL.LC;  float* SD = lds + LL.SD;  float* CH = lds + LL.CH;
-  const int nvs = M.nvs;
+  float* XS = lds + LL.XS;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
+  float* PO = lds + LL.PO;  float* LC = lds + LL.LC;  float* SD = lds + LL.SD;  float* CH = lds + LL.CH;
 
   const bool isb = lane > 0 && lane < nb;
   const int bl = isb ? lane : 0;
