@@ -861,18 +861,16 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       }
       if (!isb) { xp = mk3(0.f, 0.f, 0.f); xq.w = 1.f; xq.x = xq.y = xq.z = 0.f; }
       const uint32_t jm = lane < nb ? *(const uint32_t*)(JMP + lane * M.anc_stride) : 0u;   // rounds 0..3
+      // the partner's pose comes out of its registers with ds_bpermute (lane 0 is the world: identity)
       for (int r = 0; r < M.max_bdepth; r++) {      // max_bdepth = number of jumping rounds
-        if (lane < nb) {
-          *(float4*)(T + lane * 8) = make_float4(xp.x, xp.y, xp.z, 0.f);
-          *(float4*)(T + lane * 8 + 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
-        }
-        WSYNC();
         const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
-        const float4 ap = *(const float4*)(T + a * 8), aq = *(const float4*)(T + a * 8 + 4);
-        const q4 aqq = {aq.x, aq.y, aq.z, aq.w};
-        xp = add3(mk3(ap.x, ap.y, ap.z), qrot(aqq, xp));
+        const int src = a << 2;
+#define PULL(v_) __int_as_float(__builtin_amdgcn_ds_bpermute(src, __float_as_int(v_)))
+        const v3 ap = mk3(PULL(xp.x), PULL(xp.y), PULL(xp.z));
+        const q4 aqq = {PULL(xq.w), PULL(xq.x), PULL(xq.y), PULL(xq.z)};
+#undef PULL
+        xp = add3(ap, qrot(aqq, xp));
         xq = qmul(aqq, xq);
-        WSYNC();
       }
       xq = qnormalize(xq);
       if (CONS && lane < nb) {
@@ -941,27 +939,27 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       }
       const uint32_t jm = lane < nb ? *(const uint32_t*)(JMP + lane * M.anc_stride) : 0u;
       cv = s6add(vJ, vt);
+#define PULL6(dst_, src_, v_) do { \
+        dst_.r = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.r.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.r.y))), \
+                     __int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.r.z)))); \
+        dst_.l = mk3(__int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.l.x))), __int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.l.y))), \
+                     __int_as_float(__builtin_amdgcn_ds_bpermute(src_, __float_as_int(v_.l.z)))); } while (0)
       for (int r = 0; r < M.max_bdepth; r++) {
-        if (lane < nb) lds_put6(V + lane * 8, cv);
-        WSYNC();
         const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
-        cv = s6add(cv, lds_get6(V + a * 8));
-        WSYNC();
+        s6 o; PULL6(o, a << 2, cv);
+        cv = s6add(cv, o);
       }
-      if (lane < nb) lds_put6(V + lane * 8, cv);
-      WSYNC();
       // w = cdof_dot * qvel of this body's joint = cvel(before the joint's rotary part) x vJ
-      s6 cpar = lds_get6(V + (isb ? c_info.x : 0) * 8);
+      s6 cpar; PULL6(cpar, (isb ? c_info.x : 0) << 2, cv);
       cpar = s6add(cpar, vt);
       ca = cross_motion(cpar, vJ);
       if (!isb) { ca.r = ca.l = mk3(0.f, 0.f, 0.f); }
       for (int r = 0; r < M.max_bdepth; r++) {
-        if (lane < nb) lds_put6(T + lane * 8, ca);
-        WSYNC();
         const int a = r < 4 ? (int)((jm >> (8 * r)) & 0xff) : (lane < nb ? (int)JMP[lane * M.anc_stride + r] : 0);
-        ca = s6add(ca, lds_get6(T + a * 8));
-        WSYNC();
+        s6 o; PULL6(o, a << 2, ca);
+        ca = s6add(ca, o);
       }
+#undef PULL6
       ca.l = sub3(ca.l, mk3(M.gx, M.gy, M.gz));
       if (!isb) { cv.r = cv.l = mk3(0.f, 0.f, 0.f); }
     }
