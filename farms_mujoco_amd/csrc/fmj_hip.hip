@@ -1228,6 +1228,44 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
                 cnt += pen ? 1 : 0;
               }
             }
+            if (gi.x == FMJ_GEOM_CYLINDER) {      // rim points (the oracle's collide_plane, MuJoCo's mjc_PlaneCylinder construction)
+              const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
+              const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+              const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
+              const q4 wq = qmul(bqq, gqq);
+              const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+              const v3 nrm_ = mk3(pn.x, pn.y, pn.z);
+              v3 axis = qrot(wq, mk3(0.f, 0.f, 1.f));
+              float prjaxis = dot3(nrm_, axis);
+              if (prjaxis > 0.f) { axis = scl3(axis, -1.f); prjaxis = -prjaxis; }
+              const float dist = dot3(cen, nrm_) - pn.w;
+              v3 vec = sub3(scl3(axis, prjaxis), nrm_);
+              const float len2 = dot3(vec, vec);
+              if (len2 >= 1e-30f) vec = scl3(vec, gs.x / sqrtf(len2)); else vec = scl3(qrot(wq, mk3(1.f, 0.f, 0.f)), gs.x);
+              const float prjvec = dot3(vec, nrm_);
+              axis = scl3(axis, gs.y); prjaxis *= gs.y;
+              mu = fmaxf(pp.x, gs.w);
+              const float d0 = dist + prjaxis + prjvec;
+              if (d0 < 0.f) {
+                cq[0] = add3(cen, add3(vec, axis)); dq[0] = d0; cnt = 1;
+                const float d1 = dist - prjaxis + prjvec;
+                if (d1 < 0.f) { cq[1] = add3(cen, sub3(vec, axis)); dq[1] = d1; cnt = 2; }
+                v3 vec1 = cross(vec, axis);
+                const float l1 = sqrtf(dot3(vec1, vec1));
+                if (l1 > 1e-15f) vec1 = scl3(vec1, gs.x * 0.8660254037844386f / l1);
+                const float prjvec1 = dot3(vec1, nrm_);
+#pragma unroll
+                for (int sg = 0; sg < 2; sg++) {
+                  const float sgn = sg ? -1.f : 1.f;
+                  const float d2 = dist + prjaxis - 0.5f * prjvec + sgn * prjvec1;
+                  const v3 c2 = add3(cen, add3(scl3(vec1, sgn), sub3(axis, scl3(vec, 0.5f))));
+                  const bool pen = d2 < 0.f;
+#pragma unroll
+                  for (int k = 1; k < 4; k++) if (pen && cnt == k) { cq[k] = c2; dq[k] = d2; }
+                  cnt += pen ? 1 : 0;
+                }
+              }
+            }
           }
           int before = 0, total = 0;
 #pragma unroll
@@ -1539,9 +1577,9 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   for (int g = 0; g < m->ngeom; g++) {
     int t = m->geom_type[g];
     if (t == FMJ_GEOM_PLANE) { if (m->geom_bodyid[g] != 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: planes must be attached to the world body"); nplane++; }
-    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule / box geoms are in the HIP path");
+    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX && t != FMJ_GEOM_CYLINDER) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule / cylinder / box geoms are in the HIP path");
     else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
-    if (t == FMJ_GEOM_BOX) any_box = 1;
+    if (t == FMJ_GEOM_BOX || t == FMJ_GEOM_CYLINDER) any_box = 1;      // geoms with up to 4 contacts
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane);
   if (cons && m->ngeom > nplane && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");

@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..io.sdf import ModelSDF, Link
-from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, DEFAULT_SOLREF,
+from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, DEFAULT_SOLREF,
                      DEFAULT_SOLIMP)
 from ..units import SimulationUnitScaling
 
@@ -136,11 +136,13 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                     b.add_geom(link.name, GEOM_SPHERE, (g.size[0]*units.meters,), **gkw)
                 elif g.kind == 'capsule':
                     b.add_geom(link.name, GEOM_CAPSULE, (g.size[0]*units.meters, 0.5*g.size[1]*units.meters), **gkw)
+                elif g.kind == 'cylinder':              # reference mjcf.py:427-440: radius, half length
+                    b.add_geom(link.name, GEOM_CYLINDER, (g.size[0]*units.meters, 0.5*g.size[1]*units.meters), **gkw)
                 elif g.kind == 'box':                   # SDF box size = full edge lengths, MuJoCo box size = half extents
                     b.add_geom(link.name, GEOM_BOX, tuple(0.5*x*units.meters for x in g.size[:3]), **gkw)
                 else:
                     raise NotImplementedError(f'collision shape {g.kind!r} of link {link.name} is outside the HIP subset '
-                                              '(sphere / capsule / box against planes)')
+                                              '(sphere / capsule / cylinder / box against planes)')
         for child in sdf.get_children(link):
             add_link(child, link, link.name, sdf.get_parent_joint(child))
 
@@ -192,7 +194,7 @@ def model2mjcf_xml(m: Model) -> str:
     the body tree with explicit inertials, joints, collision geoms, the actuator triple and the sensors of
     mjcf.py:950-1002.  The text loads in MuJoCo; nothing in this package reads it back."""
     import xml.etree.ElementTree as ET
-    from ..model import JNT_FREE, JNT_SLIDE, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX
+    from ..model import JNT_FREE, JNT_SLIDE, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX
 
     def v(a):
         return ' '.join(repr(float(x)) for x in np.asarray(a).ravel())
@@ -205,7 +207,7 @@ def model2mjcf_xml(m: Model) -> str:
     ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))
     world = ET.SubElement(root, 'worldbody')
     elems = {0: world}
-    gtypes = {GEOM_PLANE: 'plane', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_BOX: 'box'}
+    gtypes = {GEOM_PLANE: 'plane', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_CYLINDER: 'cylinder', GEOM_BOX: 'box'}
     for b in range(1, m.nbody):
         e = ET.SubElement(elems[int(m.body_parentid[b])], 'body', name=m.body_names[b], pos=v(m.body_pos[b]), quat=v(m.body_quat[b]))
         elems[b] = e
@@ -227,7 +229,7 @@ def model2mjcf_xml(m: Model) -> str:
                 ET.SubElement(e, 'joint', **at)
     for g in range(m.ngeom):
         t = int(m.geom_type[g])
-        size = {GEOM_PLANE: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
+        size = {GEOM_PLANE: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
         ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]),
                       friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]), solimp=v(m.geom_solimp[g]), condim='3', margin='0')
     if m.nu:

@@ -38,7 +38,7 @@ enum {
 
 /* ---- joint / geom enums (values follow MuJoCo's mjtJoint / mjtGeom) ---------------------- */
 enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, FMJ_JNT_HINGE = 3 };
-enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_BOX = 6 };
+enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
  * reference simulation.py:157-161,176-179) */
@@ -128,10 +128,11 @@ typedef struct fmj_model {
   const double* actuator_forcerange; /* [nu,2] (task.py:279-286 rewrites this at run time) */
 
   /* collision geoms [ngeom] (config 4: animat geoms vs plane; reference mjcf.py:251-527).  Supported pairs: plane
-   * (world-attached) against sphere (1 contact), capsule (2: segment ends) and box (first 4 penetrating corners). */
+   * (world-attached) against sphere (1 contact), capsule (2: segment ends), cylinder (rim points: up to 4) and box
+   * (first 4 penetrating corners). */
   const int32_t* geom_type;     /* FMJ_GEOM_* */
   const int32_t* geom_bodyid;
-  const double* geom_size;      /* [ngeom,3] MuJoCo sizes: sphere r; capsule r, half length; box half extents */
+  const double* geom_size;      /* [ngeom,3] MuJoCo sizes: sphere r; capsule / cylinder r, half length; box half extents */
   const double* geom_pos;       /* [ngeom,3] body frame */
   const double* geom_quat;      /* [ngeom,4] */
   const double* geom_friction;  /* [ngeom,3] */

@@ -526,6 +526,44 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
         add_contact(m, w, p, g, pos, n, dist, mu, warn);
       }
     }
+  } else if (type == FMJ_GEOM_CYLINDER) {
+    /* plane - cylinder, MuJoCo's published rim-point construction (mjc_PlaneCylinder; restated, not compiled from
+     * MuJoCo): the rim point deepest into the plane on the near disk, the same point on the far disk, then two points
+     * at +-120 degrees on the near rim.  margin = 0 (reference mjcf.py:253). */
+    double axis[3] = {gm[2], gm[5], gm[8]}, vec[3], vec1[3], dif[3];
+    double prjaxis = dotn(n, axis, 3);
+    if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+    for (int k = 0; k < 3; k++) dif[k] = gpos[k] - ppos[k];
+    double dist = dotn(n, dif, 3);
+    for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
+    double len2 = dotn(vec, vec, 3);
+    if (len2 >= 1e-30) { double sc = size[0] / sqrt(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
+    else { for (int k = 0; k < 3; k++) vec[k] = gm[3 * k] * size[0]; }
+    double prjvec = dotn(vec, n, 3);
+    for (int k = 0; k < 3; k++) axis[k] *= size[1];
+    prjaxis *= size[1];
+    double d0 = dist + prjaxis + prjvec;
+    if (d0 < 0) {
+      double pos[3];
+      for (int k = 0; k < 3; k++) pos[k] = gpos[k] + vec[k] + axis[k] - n[k] * 0.5 * d0;
+      add_contact(m, w, p, g, pos, n, d0, mu, warn);
+      double d1 = dist - prjaxis + prjvec;
+      if (d1 < 0) {
+        for (int k = 0; k < 3; k++) pos[k] = gpos[k] + vec[k] - axis[k] - n[k] * 0.5 * d1;
+        add_contact(m, w, p, g, pos, n, d1, mu, warn);
+      }
+      vec1[0] = vec[1] * axis[2] - vec[2] * axis[1]; vec1[1] = vec[2] * axis[0] - vec[0] * axis[2]; vec1[2] = vec[0] * axis[1] - vec[1] * axis[0];
+      double l1 = sqrt(dotn(vec1, vec1, 3));
+      if (l1 > 1e-15) for (int k = 0; k < 3; k++) vec1[k] *= size[0] * 0.8660254037844386 / l1;
+      double prjvec1 = dotn(vec1, n, 3);
+      for (int sgn = 1; sgn >= -1; sgn -= 2) {
+        double d2 = dist + prjaxis - 0.5 * prjvec + sgn * prjvec1;
+        if (d2 < 0) {
+          for (int k = 0; k < 3; k++) pos[k] = gpos[k] + sgn * vec1[k] + axis[k] - 0.5 * vec[k] - n[k] * 0.5 * d2;
+          add_contact(m, w, p, g, pos, n, d2, mu, warn);
+        }
+      }
+    }
   } else if (type == FMJ_GEOM_BOX) {
     int cnt = 0;
     for (int corner = 0; corner < 8 && cnt < 4; corner++) {

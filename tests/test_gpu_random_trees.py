@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 
 
 def random_tree(seed, contacts=False):
-    from farms_mujoco_amd.model import ModelBuilder, euler2quat, GEOM_SPHERE, GEOM_CAPSULE, GEOM_BOX, GEOM_PLANE
+    from farms_mujoco_amd.model import ModelBuilder, euler2quat, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_PLANE
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(3, 22))
     free = bool(rng.integers(0, 2))
@@ -43,14 +43,16 @@ def random_tree(seed, contacts=False):
             b.add_body(name, parent, pos=rng.normal(size=3)*0.08, quat=euler2quat(rng.normal(size=3)*0.5), **jkw, **kw)
         names.append(name)
         if contacts and rng.random() < 0.7:
-            kind = int(rng.integers(0, 3))
+            kind = int(rng.integers(0, 4))
             gk = dict(pos=rng.normal(size=3)*0.02, quat=euler2quat(rng.normal(size=3)), friction=(float(rng.uniform(0.3, 1.0)), 0, 0))
             if kind == 0:
                 b.add_geom(name, GEOM_SPHERE, (float(rng.uniform(0.02, 0.05)),), **gk)
             elif kind == 1:
                 b.add_geom(name, GEOM_CAPSULE, (float(rng.uniform(0.015, 0.03)), float(rng.uniform(0.02, 0.06))), **gk)
-            else:
+            elif kind == 2:
                 b.add_geom(name, GEOM_BOX, tuple(rng.uniform(0.015, 0.05, 3)), **gk)
+            else:
+                b.add_geom(name, GEOM_CYLINDER, (float(rng.uniform(0.02, 0.05)), float(rng.uniform(0.01, 0.05))), **gk)
     if contacts:
         b.add_geom('world', GEOM_PLANE, (0, 0, 0), pos=(0, 0, -0.05), friction=(0.2, 0, 0))
         b.options['max_contacts'] = 32
@@ -115,7 +117,7 @@ def test_random_tree_vs_oracle(oracle, seed, two_per_wave, monkeypatch):
 
 @pytest.mark.parametrize('seed', range(100, 112))
 def test_random_tree_with_limits_and_contacts(oracle, seed):
-    """The constraint path on random trees: limited hinges, sphere / capsule / box geoms over a plane that cuts
+    """The constraint path on random trees: limited hinges, sphere / capsule / box / cylinder geoms over a plane that cuts
     through the tree; contact lists, constraint forces and the state after one and after 30 steps vs the oracle."""
     import torch
     from farms_mujoco_amd.physics import BatchedPhysics

@@ -77,3 +77,42 @@ def test_meaninertia_matches_model(oracle):
     m = salamander33(contacts=True, limits=True)
     assert abs(m.meaninertia - np.mean(np.diag(np_mass_matrix(m, m.qpos0)))) < 1e-15
     assert m.max_contacts == 32 and m.ngeom == 17
+
+
+def _prism(kind, size, quat=(1, 0, 0, 0), z=0.0, mass=0.4):
+    from farms_mujoco_amd.model import GEOM_BOX, GEOM_CYLINDER
+    b = ModelBuilder('prism', timestep=1e-3)
+    b.add_body('p', 'world', pos=(0, 0, z), quat=quat, mass=mass, inertia=(4e-4, 4e-4, 4e-4), joint='free')
+    b.add_geom('p', {'box': GEOM_BOX, 'cylinder': GEOM_CYLINDER}[kind], size, friction=(1.0, 0, 0))
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))
+    b.options['max_contacts'] = 8
+    return b.compile()
+
+
+def test_cylinder_and_box_contact_sets(oracle):
+    """Geometry of the plane-cylinder and plane-box contact sets: an upright cylinder touches with three rim points
+    120 degrees apart, a lying one along its lowest line (two points), a flat box with its four bottom corners; the
+    settled normal forces carry the weight."""
+    r, hh = 0.04, 0.03
+    up = _prism('cylinder', (r, hh), z=hh - 1e-3)
+    fd = oracle.forward_debug(up, up.qpos0, np.zeros(6))
+    assert fd['ncon'] == 3
+    p = fd['contact'][:3, :3]
+    assert np.allclose(np.linalg.norm(p[:, :2], axis=1), r, atol=1e-12) and np.allclose(fd['contact'][:3, 12], -1e-3)
+    ang = np.sort(np.arctan2(p[:, 1], p[:, 0]))
+    assert np.allclose(np.diff(ang), 2*np.pi/3, atol=1e-9)
+    c, s = np.cos(np.pi/4), np.sin(np.pi/4)
+    lying = _prism('cylinder', (r, hh), quat=(c, 0, s, 0), z=r - 2e-3)          # axis along x
+    fd = oracle.forward_debug(lying, lying.qpos0, np.zeros(6))
+    assert fd['ncon'] == 2
+    assert np.allclose(np.sort(fd['contact'][:2, 0]), [-hh, hh], atol=1e-12) and np.allclose(fd['contact'][:2, 1], 0, atol=1e-12)
+    assert np.allclose(fd['contact'][:2, 12], -2e-3)
+    box = _prism('box', (0.05, 0.03, 0.02), z=0.02 - 1e-3)
+    fd = oracle.forward_debug(box, box.qpos0, np.zeros(6))
+    assert fd['ncon'] == 4
+    assert np.allclose(np.abs(fd['contact'][:4, 0]), 0.05) and np.allclose(np.abs(fd['contact'][:4, 1]), 0.03)
+    for m in (up, box):
+        o = oracle.step(m, m.qpos0[None], np.zeros((1, 6)), n_steps=1500)
+        fd = oracle.forward_debug(m, o['qpos'][0], o['qvel'][0])
+        assert abs(fd['efc_force'][:fd['nefc']].sum() - 0.4*9.81) < 1e-3
+        assert abs(o['qvel'][0]).max() < 1e-4
