@@ -191,3 +191,16 @@ def test_mjcf_export(sdf_path, tmp_path):
     for b in range(2, m.nbody):
         parent = next(p for p in root.iter('body') if any(c is e for c in p for e in [bodies[b - 1]]))
         assert parent.get('name') == m.body_names[m.body_parentid[b]]
+
+
+def test_cylinder_collision_maps_to_radius_and_half_length(tmp_path, sdf_path):
+    """SDF <cylinder> radius / length -> MuJoCo cylinder size (radius, half length), reference mjcf.py:427-440."""
+    from farms_mujoco_amd.model import GEOM_CYLINDER
+    text = open(sdf_path).read().replace(
+        '<geometry><sphere><radius>0.02</radius></sphere></geometry>',
+        '<geometry><cylinder><radius>0.02</radius><length>0.1</length></cylinder></geometry>')
+    p = tmp_path/'cyl.sdf'
+    p.write_text(text)
+    m = sdf2model(ModelSDF.read(str(p))[0], animat_options=_options(str(p)), use_collisions=True, plane=True)
+    g = [i for i in range(m.ngeom) if m.geom_type[i] == GEOM_CYLINDER]
+    assert len(g) == 1 and np.allclose(m.geom_size[g[0]][:2], [0.02, 0.05])
