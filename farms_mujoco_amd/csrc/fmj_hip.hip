@@ -460,7 +460,7 @@ typedef const DualRound __attribute__((address_space(4)))* cround_p;   // consta
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 template <int MAXD>
-__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int lane, bool isd, int ddepth, float& dinv_mine) {
+__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth, float& dinv_mine) {
   constexpr int RS = MAXD;
   f2_t r[MAXD / 2];                                // row in registers as float pairs: the update is v_pk_fma_f32
 #pragma unroll
@@ -475,36 +475,37 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
   // members' are read, theirs are final - and every proper ancestor i of a member k (uniform lane mask) does
   // row_i -= (row_k[depth_i] / D_k) row_k.  One LDS round trip per tree level instead of one per dof.
   const cround_p RND = (cround_p)rounds;
-#define APPLY_PIVOT(p_, am_) do { \
+  // NG_ float4 groups of a row are published, read and applied: ancestors only own slots below the deepest depth, so
+  // when that depth leaves the last group empty the loop runs on MAXD / 4 - 1 groups.
+#define APPLY_PIVOT(NG_, p_, am_) do { \
     const float tk_ = HR[(p_) * RS + ddepth]; const float dki_ = DV[p_]; \
-    float4 rk_[MAXD / 4]; \
-    _Pragma("unroll") for (int g = 0; g < MAXD / 4; g++) rk_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); \
+    float4 rk_[NG_]; \
+    _Pragma("unroll") for (int g = 0; g < NG_; g++) rk_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); \
     const float t_ = mask_select(tk_ * dki_, am_); \
     const f2_t nt_ = f2_t{-t_, -t_}; \
-    _Pragma("unroll") for (int g = 0; g < MAXD / 4; g++) { \
+    _Pragma("unroll") for (int g = 0; g < NG_; g++) { \
       r[2 * g] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].x, rk_[g].y}, r[2 * g]); \
       r[2 * g + 1] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].z, rk_[g].w}, r[2 * g + 1]); } \
     diag = fmaf(-t_, tk_, diag); } while (0)
-  {
-    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2;
-    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
-#pragma unroll 1
-    for (int rd = 0; rd < nround; rd++) {
-      const int rn = rd + 1 < nround ? rd + 1 : rd;
-      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2;
-      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2];
-      if (isd) {
-#pragma unroll
-        for (int d = 0; d < MAXD; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y);
-        DV[lane] = __builtin_amdgcn_rcpf(diag);
-      }
-      WSYNC();
-      APPLY_PIVOT(p0, a0);
-      if (p1 >= 0) { APPLY_PIVOT(p1, a1); APPLY_PIVOT(p2, a2); }
-      WSYNC();
-      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2;
-    }
-  }
+#define L_ROUNDS(NG_) do { \
+    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2; \
+    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2]; \
+    _Pragma("unroll 1") for (int rd = 0; rd < nround; rd++) { \
+      const int rn = rd + 1 < nround ? rd + 1 : rd; \
+      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2; \
+      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2]; \
+      if (isd) { \
+        _Pragma("unroll") for (int d = 0; d < 4 * NG_; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y); \
+        DV[lane] = __builtin_amdgcn_rcpf(diag); \
+      } \
+      WSYNC(); \
+      APPLY_PIVOT(NG_, p0, a0); \
+      if (p1 >= 0) { APPLY_PIVOT(NG_, p1, a1); APPLY_PIVOT(NG_, p2, a2); } \
+      WSYNC(); \
+      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; \
+    } } while (0)
+  if (MAXD > 4 && maxdep <= MAXD - 4) L_ROUNDS((MAXD > 4 ? MAXD / 4 - 1 : 1)); else L_ROUNDS(MAXD / 4);
+#undef L_ROUNDS
 #undef APPLY_PIVOT
   dinv_mine = isd ? __builtin_amdgcn_rcpf(diag) : 0.f;
   // every lane's register row is final since its own round: publish it once more, scaled by 1/D, so that
@@ -1161,7 +1162,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (1) factor M, qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
       {
-        ldl_factor<MAXD>(HM, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_m);
+        ldl_factor<MAXD>(HM, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_m);
       }
       const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m, M.ancl1, M.maxdep1);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); }
@@ -1317,7 +1318,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     float my_qacc;
     {
       float dinv_mine;
-      ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_mine);
+      ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_mine);
       STAMP(9);   // L
       my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine, M.ancl1, M.maxdep1);
     }
