@@ -224,7 +224,7 @@ def main():
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b_step,
-                         'note': 'latency/VALU-issue-bound tree recursions (profiles/r01_v10_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
+                         'note': 'latency/VALU-issue-bound tree recursions (profiles/r01_v11_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:
