@@ -9,7 +9,7 @@ import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, 'csrc')
-SO_PATH = os.path.join(CSRC, 'libfmj_hip.so')
+SO_PATH = os.environ.get('FMJ_SO') or os.path.join(CSRC, 'libfmj_hip.so')      # FMJ_SO: A/B a variant build (scripts/)
 HEADER = os.path.join(_HERE, '..', 'include', 'fmj.h')
 
 _F = ctypes.POINTER(ctypes.c_float)
