@@ -57,7 +57,7 @@ class CFusedArgs(ctypes.Structure):
                 ('ctrl_step_stride', ctypes.c_int64), ('row_stride_links', ctypes.c_int64),
                 ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
                 ('row_stride_contacts', ctypes.c_int64),
-                ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave)]
+                ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP)]
 
 
 # every symbol include/fmj.h declares: name -> (restype, argtypes)
@@ -75,10 +75,14 @@ SYMBOLS = {
     'fmj_abi_version': (ctypes.c_int, []),
     'fmj_get_sensor_layout': (ctypes.c_int, [_VP, ctypes.POINTER(CSensorLayout)]),
     'fmj_kernel_info': (ctypes.c_int, [_VP, _I, _I]),
-    'fmj_set_swimming': (ctypes.c_int, [_VP, ctypes.c_int32, _I, _I, _I, _D, _D, _D, _D]),
+    'fmj_set_swimming': (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, _I, _I, _I, _D, _D, _D, _D]),
+    'fmj_set_actuator_forcerange': (ctypes.c_int, [_VP, ctypes.c_int32, _I, _D]),
+    'fmj_drag_link': (ctypes.c_int, [ctypes.c_int32, ctypes.c_int32, _VP, ctypes.c_int64, _VP, ctypes.c_int64, _D,
+                                     ctypes.c_double, ctypes.c_double, ctypes.c_double, ctypes.POINTER(CWater), _VP, _VP]),
     'fmj_set_readout_maps': (ctypes.c_int, [_VP, ctypes.c_int32, _I, ctypes.c_int32, _I]),
     'fmj_step': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, ctypes.c_int64, _VP]),
     'fmj_forward': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP]),
+    'fmj_forward_debug': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP, _I, _VP, _VP]),
     'fmj_drag': (ctypes.c_int, [_VP, ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits), _VP, _VP]),
     'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
                                         ctypes.c_int32, _VP]),
@@ -92,6 +96,7 @@ SYMBOLS = {
 }
 
 _lib = None
+ABI_VERSION = 2         # FMJ_ABI_VERSION of include/fmj.h
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
@@ -141,7 +146,7 @@ def load():
         fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
         fn.restype = res
         fn.argtypes = args
-    if lib.fmj_abi_version() != 1:
+    if lib.fmj_abi_version() != ABI_VERSION:
         raise FmjError('libfmj_hip.so ABI version mismatch; rebuild')
     _lib = lib
     return lib

@@ -127,6 +127,8 @@ struct StepArgs {
   float inv_meters, inv_velocity, inv_angvel, inv_torques, newtons, torques;
   // wave controller
   const float* w_amp; const float* w_lag; const float* w_env; float w_freq;
+  float* ctrl_out;            // fused + wave controller: ctrl of the launch's last step (physics.data.ctrl)
+  float* dbg_H; float* dbg_qfrc;   // fmj_forward_debug: rows of H = M + diag(armature + h damping) [n_envs][nv][rs], qfrc_smooth [n_envs][nv]
 };
 
 struct fmj_ctx {
@@ -144,6 +146,7 @@ struct fmj_ctx {
   std::vector<int> jnt_dofadr, jnt_type;
   int ngeom, n_contact_rows, n_pairs; std::vector<int> geom_sensor, geom_is_plane; int* d_geom_sensor; int* d_pairs;
   int* d_links_body; int* d_joints_dof;      // row -> body / dof maps of the standalone readout operator
+  std::vector<float4> h_atab; std::vector<int> a_src;   // actuator table mirror (fmj_set_actuator_forcerange)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -620,8 +623,9 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
 }
 
 // One contact-sensor row (reference sensors.pyx:20-137,158-182): accumulate every contact whose keys hit `row`.
-// Contact records: pos(3) frame(9) force(3: normal,t1,t2) geom2 bits.  geom1 is always the plane here, which is
-// never a sensor key of its own, so of the four reference keys only (g2,-1,+1) and (g1,g2,-1) can match.
+// Contact records: pos(3) frame(9) force(3: normal,t1,t2) int32 geom1 << 16 | geom2.  The four keys of
+// sensors.pyx:163-169 in the reference's order: (g1,g2) -1, (g2,g1) +1, (g1,-1) -1, (g2,-1) +1; a key that maps to
+// `row` adds the contact once (a contact can hit one row through several keys, as in the reference).
 __device__ __forceinline__ void contact_row(const float* C, int nc, int row, const int* geom_sensor, int n_pairs, const int* pairs,
                                             float inv_newtons, float inv_meters, float* out) {
   float acc[12]; float norm_sum = 0.f;
@@ -629,25 +633,30 @@ __device__ __forceinline__ void contact_row(const float* C, int nc, int row, con
   for (int k = 0; k < 12; k++) acc[k] = 0.f;
   for (int c = 0; c < nc; c++) {
     const float* ct = C + c * 16;
-    const int g2 = __float_as_int(ct[15]);
-    for (int key = 0; key < 2; key++) {
-      int sign = 0;
-      if (key == 0) { if (geom_sensor[g2] == row) sign = +1; }
-      else { for (int p = 0; p < n_pairs; p++) if (pairs[3 * p + 2] == row && pairs[3 * p + 1] == g2) sign = -1; }
-      if (!sign) continue;
-      float tot[3];
-#pragma unroll
-      for (int i = 0; i < 3; i++) {                                            // store_forces, sensors.pyx:33-52
-        const float reaction = sign * ct[12] * ct[3 + i];
-        const float friction = sign * ct[13] * ct[6 + i] + sign * ct[14] * ct[9 + i];
-        tot[i] = reaction + friction;
-        acc[FMJ_CONTACT_REACTION + i] += reaction; acc[FMJ_CONTACT_FRICTION + i] += friction; acc[FMJ_CONTACT_TOTAL + i] += tot[i];
-      }
-      const float nrm = sqrtf(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);
-#pragma unroll
-      for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] += nrm * ct[i];
-      norm_sum += nrm;
+    const int gg = __float_as_int(ct[15]);
+    const int g1 = gg >> 16, g2 = gg & 0xffff;
+    int nneg = 0, npos = 0;                       // matching keys of sign -1 / +1
+    for (int p = 0; p < n_pairs; p++) {
+      if (pairs[3 * p + 2] != row) continue;
+      if (pairs[3 * p] == g1 && pairs[3 * p + 1] == g2) nneg++;
+      if (pairs[3 * p] == g2 && pairs[3 * p + 1] == g1) npos++;
     }
+    if (geom_sensor[g1] == row) nneg++;
+    if (geom_sensor[g2] == row) npos++;
+    if (nneg + npos == 0) continue;
+    float tot[3];
+    const float sgn = (float)(npos - nneg), cnt = (float)(npos + nneg);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {                                            // store_forces, sensors.pyx:33-52
+      const float reaction = ct[12] * ct[3 + i];
+      const float friction = ct[13] * ct[6 + i] + ct[14] * ct[9 + i];
+      tot[i] = reaction + friction;
+      acc[FMJ_CONTACT_REACTION + i] += sgn * reaction; acc[FMJ_CONTACT_FRICTION + i] += sgn * friction; acc[FMJ_CONTACT_TOTAL + i] += sgn * tot[i];
+    }
+    const float nrm = cnt * sqrtf(tot[0] * tot[0] + tot[1] * tot[1] + tot[2] * tot[2]);   // |+-total| once per matching key
+#pragma unroll
+    for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] += nrm * ct[i];
+    norm_sum += nrm;
   }
   if (norm_sum > 0.f) { for (int i = 0; i < 3; i++) acc[FMJ_CONTACT_POSITION + i] /= norm_sum; }     // sensors.pyx:85-88
 #pragma unroll
@@ -659,14 +668,14 @@ __device__ __forceinline__ void contact_row(const float* C, int nc, int row, con
 // Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
 // forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
 // every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
-__device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const StepArgs& A, int env, int it, bool isb,
+__device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const StepArgs& A, int env, int it, bool isb, bool frozen,
                                                     int link_row, int swim_slot, v3 xpos, q4 xquat, v3 xipos, v3 linvel,
                                                     v3 angvel, float* xf) {
   const int index = it % A.buffer_size;
   const v3 r_com = scl3(xipos, A.inv_meters), r_urdf = scl3(xpos, A.inv_meters);
   const v3 r_lin = scl3(linvel, A.inv_velocity), r_ang = scl3(angvel, A.inv_angvel);
   const fq r_q = {xquat.x, xquat.y, xquat.z, xquat.w};   // wxyz -> xyzw (physics.py:458)
-  if (A.do_readout && isb && link_row >= 0) {
+  if (A.do_readout && isb && !frozen && link_row >= 0) {
     float* row = A.links + ((size_t)index * A.row_stride_links + (size_t)env * M.n_links * FMJ_LINK_SIZE) + link_row * FMJ_LINK_SIZE;
     *(float4*)(row + 0) = make_float4(r_com.x, r_com.y, r_com.z, r_q.x);
     *(float4*)(row + 4) = make_float4(r_q.y, r_q.z, r_q.w, r_urdf.x);
@@ -681,10 +690,12 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
       const float4 s0 = STAB(swim_slot, 0), s1 = STAB(swim_slot, 1), s2 = STAB(swim_slot, 2);
       v3 fo, to, fw, tw;
       if (drag_link_same_frames(r_com, xquat, r_lin, r_ang, s0, s1, s2.x, A, &fo, &fw, &to, &tw)) {
-        float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
-        *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
-        *(float2*)(xr + 2) = make_float2(fo.z, to.x);
-        *(float2*)(xr + 4) = make_float2(to.y, to.z);
+        if (!frozen) {
+          float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
+          *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
+          *(float2*)(xr + 2) = make_float2(fo.z, to.x);
+          *(float2*)(xr + 4) = make_float2(to.y, to.z);
+        }
         xf[0] = fw.x * A.newtons; xf[1] = fw.y * A.newtons; xf[2] = fw.z * A.newtons;
         xf[3] = tw.x * A.torques; xf[4] = tw.y * A.torques; xf[5] = tw.z * A.torques;
       }
@@ -736,6 +747,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int dparent = (CONS && isd) ? DTABI(dl, 2).w : 0;
 
   // ---- load tables + state -------------------------------------------------------------------------
+  int warn = 0;
   {
     uint32_t* jw = (uint32_t*)(lds + LL.ANC);
     const int nw = r4(nb * M.anc_stride) / 4;
@@ -744,8 +756,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   {
     const float* gq = A.qpos + (size_t)env * nq;
     const float* gv = A.qvel + (size_t)env * nv;
-    for (int i = lane; i < nq; i += 64) QP[i] = gq[i];
-    for (int i = lane; i < nv; i += 64) QV[i] = gv[i];
+    for (int i = lane; i < nq; i += 64) { const float v = gq[i]; QP[i] = v; if (!(fabsf(v) <= 1e10f)) warn |= FMJ_WARN_BADQPOS; }   // mj_checkPos
+    for (int i = lane; i < nv; i += 64) { const float v = gv[i]; QV[i] = v; if (!(fabsf(v) <= 1e10f)) warn |= FMJ_WARN_BADQVEL; }   // mj_checkVel
     if (lane < 8) VT[lane] = 0.f;
     if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
     if (CONS) for (int i = lane; i < (nv * nv + 3) / 4; i += 64) ((uint32_t*)LC)[i] = ((const uint32_t*)M.lcad)[i];
@@ -783,7 +795,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
     for (int k = 0; k < 6; k++) xf[k] = x[k];
   }
-  int warn = 0;
+  // An env with a bad-state bit is frozen (include/fmj.h): it is not integrated and writes no rows, from the step that
+  // finds the bad value on and in later launches until the caller clears its status word.
+  bool frozen = (A.status[env] & FMJ_WARN_FREEZE) != 0 || __any((warn & FMJ_WARN_FREEZE) != 0);
+  int steps_done = 0;
   WSYNC();
 #ifdef FMJ_STAMPS
   float stamp_acc[NSTAMP];
@@ -795,6 +810,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int lane_outer = lane;
 #pragma unroll 1
   for (int step = 0; step < A.n_steps; step++) {
+    if (frozen) break;
     // per-lane LDS/global addresses are recomputed every step instead of being hoisted and spilled
     const int lane = opaque(lane_outer);
     const int it = A.iteration0 + step;
@@ -807,7 +823,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       const float4 c0 = *(const float4*)(CY + cl * 16), c1 = *(const float4*)(CY + cl * 16 + 4);
       const float4 c2 = *(const float4*)(CY + cl * 16 + 8), c3 = *(const float4*)(CY + cl * 16 + 12);
       const q4 cq = {c0.w, c1.x, c1.y, c1.z};
-      emit_links_and_drag(M, A, env, it, isb, ci2.z, ci2.w, mk3(c0.x, c0.y, c0.z), cq, mk3(c1.w, c2.x, c2.y),
+      emit_links_and_drag(M, A, env, it, isb, false, ci2.z, ci2.w, mk3(c0.x, c0.y, c0.z), cq, mk3(c1.w, c2.x, c2.y),
                           mk3(c2.z, c2.w, c3.x), mk3(c3.y, c3.z, c3.w), xf);
     }
     STAMP(0);   // emit links + drag
@@ -1103,6 +1119,14 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         }
         qfrc += asum;
         cy_actsum = asum * A.inv_torques;
+        if (FUSED && A.controller == 1 && last && A.ctrl_out) {     // what task.py:288-346 leaves in physics.data.ctrl
+#pragma unroll
+          for (int a = 0; a < 4; a++) if (a < d_act.y) {
+            const int src = __float_as_int(ATAB(d_act.x + a, 2).x);
+            const float amp = A.w_amp[src];
+            A.ctrl_out[(size_t)env * nu + src] = amp != 0.f ? amp * sinf(cbase - A.w_lag[src]) : 0.f;
+          }
+        }
         if (last) {
           float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;   // actuatorfrc
           if (0 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 0, 2).x)] = af0;
@@ -1155,6 +1179,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     }
     WSYNC();
     STAMP(8);   // M
+    if (!FUSED && A.dbg_H) {      // fmj_forward_debug: the assembled rows and the right-hand side, before any factorisation
+      for (int i = lane; i < nv * RS; i += 64) A.dbg_H[(size_t)env * nv * RS + i] = HR[i];
+      if (isd) A.dbg_qfrc[(size_t)env * nv + lane] = qfrc;
+    }
     // ---- constraints (CONS instantiation only): qfrc_constraint from limits + plane contacts via PGS
     float qfrc_c = 0.f;
     if (CONS) {
@@ -1325,11 +1353,15 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
     const float hstep = A.integrate ? M.h : 0.f;     // fmj_forward: mj_forward only
+    const float pre_qd = isd ? QV[lane] : 0.f;
+    const float nvel = pre_qd + hstep * my_qacc;
     if (isd) {
-      if (!(fabsf(my_qacc) <= 1e10f)) warn |= FMJ_WARN_BADQACC;
+      if (!(fabsf(my_qacc) <= 1e10f)) warn |= FMJ_WARN_BADQACC;      // mj_checkAcc
+      if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
+    }
+    if (__any((warn & FMJ_WARN_FREEZE) != 0)) frozen = true;         // the state stays at its last finite values
+    if (isd && !frozen) {
       XV[lane] = my_qacc;
-      const float pre_qd = QV[lane];
-      const float nvel = pre_qd + hstep * my_qacc;
       QV[lane] = nvel;
       if (d_scalar) {
         const float pre_q = QP[d_qadr];
@@ -1339,10 +1371,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           s[0] = pre_q; s[1] = pre_qd; if (!CONS) s[2] = 0.f;
         }
       }
-      if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
     }
+    if (!frozen) steps_done++;
     WSYNC();
-    if (jtype == FMJ_JNT_FREE && A.integrate) {     // free joint position update (lane = root body)
+    if (jtype == FMJ_JNT_FREE && A.integrate && !frozen) {     // free joint position update (lane = root body)
       QP[qadr] += M.h * QV[dadr]; QP[qadr + 1] += M.h * QV[dadr + 1]; QP[qadr + 2] += M.h * QV[dadr + 2];
       const v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
       const float n = sqrtf(dot3(w, w));
@@ -1361,15 +1393,16 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   float* ov = A.qvel + (size_t)env * nv;
   for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
   for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
-  if (A.qacc) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
-  if (CONS) for (int i = lane; i < nv; i += 64) A.qacc_warmstart[(size_t)env * nv + i] = QW[i];
+  if (A.qacc && steps_done > 0) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
+  // mj_step saves qacc as the next warm start when it advances the state; mj_forward alone does not
+  if (CONS && !frozen && A.integrate) for (int i = lane; i < nv; i += 64) A.qacc_warmstart[(size_t)env * nv + i] = QW[i];
 #ifdef FMJ_STAMPS
   if (env == 0 && lane == 0 && A.qacc) {
 #pragma unroll
     for (int i = 0; i < NSTAMP; i++) A.qacc[i] = stamp_acc[i];
   }
 #endif
-  if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * A.n_steps;
+  if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * steps_done;
   if (__ballot(warn != 0)) {
     int w = warn;
 #pragma unroll
@@ -1429,10 +1462,32 @@ __global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const St
   }
 }
 
+// drag_forces (reference drag.pyx:152-268) of one link in every env: thread = env, rows addressed by an env stride
+__global__ void __launch_bounds__(256) fmj_drag_link_kernel(const int n_envs, const float* links_row, const long long links_stride,
+                                                            float* xfrc_row, const long long xfrc_stride, const float4 c0,
+                                                            const float4 c1, const float density, const StepArgs A, int* hydro) {
+  const int env = blockIdx.x * 256 + threadIdx.x;
+  if (env >= n_envs) return;
+  const float* row = links_row + (size_t)env * links_stride;
+  v3 com = mk3(row[FMJ_LINK_COM_POS], row[FMJ_LINK_COM_POS + 1], row[FMJ_LINK_COM_POS + 2]);
+  fq comq = {row[FMJ_LINK_COM_QUAT], row[FMJ_LINK_COM_QUAT + 1], row[FMJ_LINK_COM_QUAT + 2], row[FMJ_LINK_COM_QUAT + 3]};
+  fq urdfq = {row[FMJ_LINK_URDF_QUAT], row[FMJ_LINK_URDF_QUAT + 1], row[FMJ_LINK_URDF_QUAT + 2], row[FMJ_LINK_URDF_QUAT + 3]};
+  v3 lin = mk3(row[FMJ_LINK_COM_LINVEL], row[FMJ_LINK_COM_LINVEL + 1], row[FMJ_LINK_COM_LINVEL + 2]);
+  v3 ang = mk3(row[FMJ_LINK_COM_ANGVEL], row[FMJ_LINK_COM_ANGVEL + 1], row[FMJ_LINK_COM_ANGVEL + 2]);
+  v3 fo, to;
+  const bool applied = drag_link(com, urdfq, comq, lin, ang, c0, c1, density, A, &fo, &to);
+  if (applied) {
+    float* xr = xfrc_row + (size_t)env * xfrc_stride;
+    xr[0] = fo.x; xr[1] = fo.y; xr[2] = fo.z; xr[3] = to.x; xr[4] = to.y; xr[5] = to.z;
+  }
+  if (hydro) hydro[env] = applied ? 1 : 0;
+}
+
 // physics2data (reference physics.py:527-545): lane = link row, then lane = joint row
 __global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, const StepArgs A, const int links_only,
                                                                const int* links_body, const int* joints_dof) {
   const int env = blockIdx.x, nb = M.nbody;
+  if (A.status[env] & FMJ_WARN_FREEZE) return;         // a frozen env writes no rows (include/fmj.h)
   const float* sd = A.sensordata + (size_t)env * M.nsensordata;
   for (int i = threadIdx.x; i < M.n_links; i += 64) {
     const int b = links_body[i];
@@ -1470,6 +1525,7 @@ __global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, 
 __global__ void __launch_bounds__(64) fmj_contacts2data_kernel(const DevModel M, const StepArgs A, const int n_rows,
                                                                 const int* geom_sensor, const int n_pairs, const int* pairs) {
   const int env = blockIdx.x;
+  if (A.status && (A.status[env] & FMJ_WARN_FREEZE)) return;
   const int nc = A.ncon[env];
   const float* C = A.contact + (size_t)env * M.max_contacts * 16;
   for (int row = threadIdx.x; row < n_rows; row += 64)
@@ -1750,6 +1806,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   {
     int nlimj = 0; for (int j = 0; j < nj; j++) nlimj += (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE);
     D.maxefc = cons ? nlimj + 4 * D.max_contacts : 0;
+    // the HBM constraint path keeps A in rows of AG_LD floats and three 64-row slots per lane (fmj_cons_rows.inc)
+    if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
   }
   D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
@@ -1810,6 +1868,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   std::vector<float4> gtab(g_info.size() * GT_STRIDE), ptab(p_plane.size() * PT_STRIDE);
   for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
   for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; }
+  c->h_atab = atab; c->a_src = a_src;
   UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(mtab, mtab); UP(gtab, gtab); UP(ptab, ptab);
   {   // two envs per wave: bodies and the dofs minus a free root's translational dofs must fit 32 lanes
     const int t0 = D.root_free ? 3 : 0;
@@ -1950,25 +2009,24 @@ int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threa
   return FMJ_OK;
 }
 
-int fmj_set_swimming(fmj_ctx* c, int32_t ns, const int32_t* links_index, const int32_t* xfrc_index,
+int fmj_set_swimming(fmj_ctx* c, int32_t ns, int32_t n_xfrc_rows, const int32_t* links_index, const int32_t* xfrc_index,
                      const int32_t* body_index, const double* coefficients, const double* masses,
                      const double* heights, const double* densities) {
-  if (!c || ns < 0 || (ns > 0 && (!links_index || !xfrc_index || !body_index || !coefficients || !masses || !heights || !densities)))
+  if (!c || ns < 0 || n_xfrc_rows < 0 || (ns > 0 && (!links_index || !xfrc_index || !body_index || !coefficients || !masses || !heights || !densities)))
     return set_err(FMJ_ERR_ARG, "fmj_set_swimming: NULL argument");
   HIP_TRY(hipSetDevice(c->device));
   std::vector<float4> c0(ns ? ns : 1), c1(ns ? ns : 1), c2(ns ? ns : 1);
   for (int b = 0; b < 64; b++) c->h_b_info2[4 * b + 3] = -1;
-  int max_x = 0;
   for (int s = 0; s < ns; s++) {
     int b = body_index[s];
     if (b < 1 || b >= c->nbody) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: body index out of range");
-    if (links_index[s] < 0 || links_index[s] >= c->dm.n_links || xfrc_index[s] < 0) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: row index out of range");
+    if (links_index[s] < 0 || links_index[s] >= c->dm.n_links || xfrc_index[s] < 0 || xfrc_index[s] >= n_xfrc_rows)
+      return set_err(FMJ_ERR_ARG, "fmj_set_swimming: row index out of range");
     if (c->h_b_info2[4 * b + 2] != links_index[s]) return set_err(FMJ_ERR_ARG, "fmj_set_swimming: links_index must be the readout row of the same body (call fmj_set_readout_maps first)");
     const double* k = coefficients + 6 * s;
     c0[s] = f4(k[0], k[1], k[2], masses[s]); c1[s] = f4(k[3], k[4], k[5], heights[s]);
     c2[s] = make_float4((float)densities[s], ibits(links_index[s]), ibits(xfrc_index[s]), ibits(b));
     c->h_b_info2[4 * b + 3] = s;
-    if (xfrc_index[s] + 1 > max_x) max_x = xfrc_index[s] + 1;
   }
   std::vector<float4> stab((ns ? ns : 1) * ST_STRIDE, f4(0, 0, 0, 0));
   for (int s2 = 0; s2 < ns; s2++) { stab[s2 * ST_STRIDE] = c0[s2]; stab[s2 * ST_STRIDE + 1] = c1[s2]; stab[s2 * ST_STRIDE + 2] = c2[s2]; }
@@ -1976,7 +2034,21 @@ int fmj_set_swimming(fmj_ctx* c, int32_t ns, const int32_t* links_index, const i
   if ((rc = upload(c, stab, &c->dm.stab))) return rc;
   if ((rc = sync_tables(c))) return rc;
   c->dm.ns = ns;
-  if (max_x > c->dm.n_xfrc) c->dm.n_xfrc = max_x;
+  c->dm.n_xfrc = n_xfrc_rows;       // env stride of the xfrc rows = rows the caller's tensor holds per env
+  return FMJ_OK;
+}
+
+int fmj_set_actuator_forcerange(fmj_ctx* c, int32_t nu, const int32_t* forcelimited, const double* forcerange) {
+  if (!c || !forcelimited || !forcerange) return set_err(FMJ_ERR_ARG, "fmj_set_actuator_forcerange: NULL argument");
+  if (nu != c->nu) return set_err(FMJ_ERR_ARG, "fmj_set_actuator_forcerange: nu does not match the model");
+  HIP_TRY(hipSetDevice(c->device));
+  for (size_t a = 0; a < c->a_src.size(); a++) {      // table order = sorted by dof; a_src names the model's actuator
+    const int src = c->a_src[a];
+    float4& lim = c->h_atab[a * AT_STRIDE + 1];
+    lim.z = forcelimited[src] ? (float)forcerange[2 * src] : -3.0e38f;
+    lim.w = forcelimited[src] ? (float)forcerange[2 * src + 1] : 3.0e38f;
+  }
+  HIP_TRY(hipMemcpy((void*)c->dm.atab, c->h_atab.data(), c->h_atab.size() * sizeof(float4), hipMemcpyHostToDevice));
   return FMJ_OK;
 }
 
@@ -1998,7 +2070,6 @@ int fmj_set_readout_maps(fmj_ctx* c, int32_t n_links, const int32_t* links_body,
   { int rc2 = sync_tables(c); if (rc2) return rc2; }
   c->dm.n_links = n_links; c->dm.n_joints = n_joints;
   { int rc3 = sync_readout_maps(c); if (rc3) return rc3; }
-  if (c->dm.n_xfrc < n_links) c->dm.n_xfrc = n_links;
   return FMJ_OK;
 }
 
@@ -2044,6 +2115,17 @@ int fmj_forward(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, void* 
   return launch_step(c, false, A, stream);
 }
 
+int fmj_forward_debug(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, float* H_rows, int32_t* row_stride,
+                      float* qfrc_smooth, void* stream) {
+  if (!c || !H_rows || !qfrc_smooth) return set_err(FMJ_ERR_ARG, "fmj_forward_debug: NULL argument");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_forward_debug: qpos_spring required (model has joint stiffness)");
+  A.n_steps = 1; A.integrate = 0; A.disable_actuation = disable_actuation; A.dbg_H = H_rows; A.dbg_qfrc = qfrc_smooth;
+  if (row_stride) *row_stride = c->dm.rs;
+  HIP_TRY(hipSetDevice(c->device));
+  return launch_step(c, false, A, stream);
+}
+
 int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void* stream) {
   if (!c || !a) return set_err(FMJ_ERR_ARG, "fmj_step_fused: NULL argument");
   StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
@@ -2065,6 +2147,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   }
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
+  A.ctrl_out = a->controller == 1 ? a->ctrl_out : nullptr;
   HIP_TRY(hipSetDevice(c->device));
   return launch_step(c, true, A, stream);
 }
@@ -2077,6 +2160,23 @@ int fmj_drag(fmj_ctx* c, const fmj_rows* rows, const fmj_water* water, const fmj
   fill_units(&A, units); fill_water(&A, water);
   HIP_TRY(hipSetDevice(c->device));
   hipLaunchKernelGGL(fmj_drag_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_drag_link(int32_t n_envs, int32_t device, const float* links_row, int64_t links_env_stride, float* xfrc_row,
+                  int64_t xfrc_env_stride, const double* coefficients, double mass, double height, double density,
+                  const fmj_water* water, int32_t* hydro, void* stream) {
+  if (n_envs <= 0 || !links_row || !xfrc_row || !coefficients || !water) return set_err(FMJ_ERR_ARG, "fmj_drag_link: NULL argument or n_envs <= 0");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return set_err(FMJ_ERR_NODEVICE, "fmj_drag_link: no HIP device visible");
+  if (device < 0 || device >= ndev) return set_err(FMJ_ERR_ARG, "fmj_drag_link: bad device ordinal");
+  HIP_TRY(hipSetDevice(device));
+  StepArgs A; memset(&A, 0, sizeof A);
+  fill_water(&A, water);
+  const float4 c0 = f4(coefficients[0], coefficients[1], coefficients[2], mass), c1 = f4(coefficients[3], coefficients[4], coefficients[5], height);
+  hipLaunchKernelGGL(fmj_drag_link_kernel, dim3((n_envs + 255) / 256), dim3(256), 0, (hipStream_t)stream, (int)n_envs, links_row,
+                     (long long)links_env_stride, xfrc_row, (long long)xfrc_env_stride, c0, c1, (float)density, A, (int*)hydro);
   HIP_TRY(hipGetLastError());
   return FMJ_OK;
 }
@@ -2114,7 +2214,7 @@ int fmj_contacts2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const
   if (!c || !d || !rows || !units || !rows->contacts || !d->contact || !d->ncon) return set_err(FMJ_ERR_ARG, "fmj_contacts2data: NULL argument");
   if (!c->d_geom_sensor) return set_err(FMJ_ERR_ARG, "fmj_contacts2data: call fmj_set_contact_maps first");
   StepArgs A; memset(&A, 0, sizeof A);
-  A.n_envs = c->n_envs; A.contact = d->contact; A.ncon = d->ncon; A.contacts_rows = rows->contacts;
+  A.n_envs = c->n_envs; A.contact = d->contact; A.ncon = d->ncon; A.contacts_rows = rows->contacts; A.status = d->status;
   fill_units(&A, units);
   HIP_TRY(hipSetDevice(c->device));
   hipLaunchKernelGGL(fmj_contacts2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, c->n_contact_rows,

@@ -22,7 +22,7 @@ import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 5, 6
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 DEFAULT_SOLREF = (0.02, 1.0)
 DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
@@ -179,15 +179,20 @@ class ModelBuilder:
                             friction=np.asarray(friction, float), solref=np.asarray(solref, float),
                             solimp=np.asarray(solimp, float)))
 
-    def add_joint_actuators(self, joint_name, kp=0.0, kv=0.0, forcerange=None):
-        """The position / velocity / motor triple of reference mjcf.py:819-866."""
-        fr = (0.0, 0.0) if forcerange is None else tuple(forcerange)
-        lim = forcerange is not None
-        for tag, gain, bias in (('position', kp, (0.0, -kp, 0.0)), ('velocity', kv, (0.0, 0.0, -kv)),
-                                ('torque', 1.0, (0.0, 0.0, 0.0))):
+    def add_joint_actuators(self, joint_name, kp=0.0, kv=0.0, forcerange=None, pos_limits=None, vel_limits=None):
+        """The position / velocity / motor triple of reference mjcf.py:819-866.  ``forcerange`` = the motor's
+        ``limits_torque`` applied to all three (:855-865); ``pos_limits`` / ``vel_limits`` = dict(ctrllimited, ctrlrange,
+        forcelimited, forcerange) of the ``act_pos_*`` / ``act_vel_*`` options (:675-684,829-832,844-847)."""
+        none = dict(ctrllimited=False, ctrlrange=(0.0, 0.0), forcelimited=False, forcerange=(0.0, 0.0))
+        for tag, gain, bias, lim in (('position', kp, (0.0, -kp, 0.0), pos_limits), ('velocity', kv, (0.0, 0.0, -kv), vel_limits),
+                                     ('torque', 1.0, (0.0, 0.0, 0.0), None)):
+            lim = dict(none, **(lim or {}))
+            if forcerange is not None:
+                lim.update(forcelimited=True, forcerange=tuple(forcerange))
             self.actuators.append(dict(name=f'actuator_{tag}_{joint_name}', joint=joint_name, tag=tag,
-                                       gain=float(gain), bias=bias, ctrllimited=False, ctrlrange=(0.0, 0.0),
-                                       forcelimited=lim, forcerange=fr))
+                                       gain=float(gain), bias=bias, ctrllimited=bool(lim['ctrllimited']),
+                                       ctrlrange=tuple(lim['ctrlrange']), forcelimited=bool(lim['forcelimited']),
+                                       forcerange=tuple(lim['forcerange'])))
 
     def add_position_actuator(self, joint_name, kp):
         """Compact layout: only the position actuator (SURVEY Appendix D allows nu = n_joints)."""

@@ -133,12 +133,23 @@ class BatchedPhysics:
         _lib.check(self._lib.fmj_set_readout_maps(self._ctx, len(self.links_body), self.links_body.ctypes.data_as(I),
                                                   len(self.joints_jnt), self.joints_jnt.ctypes.data_as(I)))
 
-    def set_swimming(self, links_index, xfrc_index, body_index, coefficients, masses, heights, densities):
+    def set_swimming(self, n_xfrc_rows, links_index, xfrc_index, body_index, coefficients, masses, heights, densities):
+        """``n_xfrc_rows`` = len(data.sensors.xfrc.names): the per-env row count of the xfrc tensor."""
         I, D = ctypes.POINTER(ctypes.c_int32), ctypes.POINTER(ctypes.c_double)
         a = [np.ascontiguousarray(x, np.int32) for x in (links_index, xfrc_index, body_index)]
         b = [np.ascontiguousarray(x, np.float64) for x in (coefficients, masses, heights, densities)]
-        _lib.check(self._lib.fmj_set_swimming(self._ctx, len(a[0]), *[x.ctypes.data_as(I) for x in a],
+        _lib.check(self._lib.fmj_set_swimming(self._ctx, len(a[0]), int(n_xfrc_rows), *[x.ctypes.data_as(I) for x in a],
                                               *[x.ctypes.data_as(D) for x in b]))
+
+    def set_actuator_forcerange(self, forcelimited, forcerange):
+        """Rewrite ``model.actuator_forcelimited`` / ``actuator_forcerange`` and refresh the device tables (the
+        run-time edit of reference task.py:279-286)."""
+        m = self.model
+        m.actuator_forcelimited = np.ascontiguousarray(forcelimited, np.int32).reshape(m.nu)
+        m.actuator_forcerange = np.ascontiguousarray(forcerange, np.float64).reshape(m.nu, 2)
+        _lib.check(self._lib.fmj_set_actuator_forcerange(
+            self._ctx, m.nu, m.actuator_forcelimited.ctypes.data_as(ctypes.POINTER(ctypes.c_int32)),
+            m.actuator_forcerange.ctypes.data_as(ctypes.POINTER(ctypes.c_double))))
 
     def set_contact_maps(self, n_rows, geom_sensor, pairs=()):
         """geompair2data (reference physics.py:360-382): geom -> contact sensor row for keys (geom, -1), plus explicit

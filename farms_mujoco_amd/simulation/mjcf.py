@@ -42,6 +42,19 @@ def get_local_transform(parent_pose, child_pose):
     return local[:3, -1], local[:3, :3]
 
 
+def check_supported_options(simulation_options):
+    """The step always runs semi-implicit Euler with a pyramidal cone and PGS; the reference forwards
+    ``simulation_options.integrator / cone / solver`` to MuJoCo's option block (mjcf.py:1342-1365), so any other
+    request would silently run different physics: refuse it."""
+    if simulation_options is None:
+        return
+    for name, supported in (('integrator', 'euler'), ('cone', 'pyramidal'), ('solver', 'pgs')):
+        value = getattr(simulation_options, name, None)
+        if value is not None and str(value).lower() != supported:
+            raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {supported!r} only '
+                                      '(Euler with implicit joint damping, pyramidal friction cone, PGS)')
+
+
 def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     """Compile one animat (reference sdf2mjcf, mjcf.py:647-1035 + the animat part of setup_mjcf_xml :1406-1481)."""
     from ..model import mat2quat
@@ -55,7 +68,16 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     friction = kwargs.pop('friction', [0, 0, 0])
     solref = kwargs.pop('solref', None)
     solimp = kwargs.pop('solimp', None)
+    # actuator ctrl / force limit options (reference mjcf.py:675-684)
+    act_pos = dict(ctrllimited=kwargs.pop('act_pos_ctrllimited', False), ctrlrange=kwargs.pop('act_pos_ctrlrange', [-1e6, 1e6]),
+                   forcelimited=kwargs.pop('act_pos_forcelimited', False), forcerange=kwargs.pop('act_pos_forcerange', [-1e6, 1e6]))
+    act_vel = dict(ctrllimited=kwargs.pop('act_vel_ctrllimited', False), ctrlrange=kwargs.pop('act_vel_ctrlrange', [-1e6, 1e6]),
+                   forcelimited=kwargs.pop('act_vel_forcelimited', False), forcerange=kwargs.pop('act_vel_forcerange', [-1e6, 1e6]))
     assert not kwargs, kwargs
+    check_supported_options(simulation_options)
+    if animat_options is not None and getattr(animat_options.morphology, 'self_collisions', None):
+        raise NotImplementedError('morphology.self_collisions (reference mjcf.py:1012-1033: explicit geom-geom contact pairs) '
+                                  'is outside the HIP subset: collision geoms only collide with world-attached planes')
 
     timestep = 1e-3
     gravity = [0.0, 0.0, -9.81]
@@ -70,6 +92,9 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     link_opts = {l.name: l for l in animat_options.morphology.links} if animat_options is not None else {}
     joint_opts = {j.name: j for j in animat_options.morphology.joints} if animat_options is not None else {}
     motors = {m_.joint_name: m_ for m_ in animat_options.control.motors} if animat_options is not None else {}
+    joints_equations = {m_.joint_name: m_.equation for m_ in motors.values() if hasattr(m_, 'equation')}
+    muscles = ({mu_.joint_name: mu_ for mu_ in animat_options.control.muscles}
+               if animat_options is not None and getattr(animat_options.control, 'muscles', None) is not None else {})
 
     # wrapper body of the model with the free joint (reference mjcf.py:176-179,716-726); spawn pose: :1409-1413
     spawn = animat_options.spawn.pose if animat_options is not None and getattr(animat_options, 'spawn', None) else sdf.pose
@@ -114,9 +139,14 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                     jkw['margin'] = extras['margin']
                 jkw['qpos0'] = 0.0
             mo = motors.get(joint.name)
-            if mo is not None and getattr(mo, 'passive', None) is not None and mo.passive.is_passive:     # :1456-1462
+            if (mo is not None and hasattr(mo, 'equation') and getattr(mo, 'passive', None) is not None
+                    and mo.passive.is_passive):                                                    # :1448-1462
                 stiffness += mo.passive.stiffness_coefficient*units.angular_stiffness
                 damping += mo.passive.damping_coefficient*units.angular_damping
+            mu_ = muscles.get(joint.name)
+            if mu_ is not None and 'ekeberg' in joints_equations[joint.name]:                      # :1464-1481
+                stiffness += mu_.beta*mu_.gamma*units.angular_stiffness
+                damping += mu_.delta*units.angular_damping
             jkw.update(stiffness=stiffness, damping=damping)
         b.add_body(link.name, parent_name, **kw, **jkw)
         lo = link_opts.get(link.name)
@@ -162,7 +192,10 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
             lim = getattr(mo, 'limits_torque', None) if mo is not None else None
             b.add_joint_actuators(jn, kp=gains[0]*units.torques if gains else 0.0,
                                   kv=gains[1]*units.angular_damping if gains else 0.0,
-                                  forcerange=[t*units.torques for t in lim] if lim is not None else None)
+                                  forcerange=[t*units.torques for t in lim] if lim is not None else None,
+                                  pos_limits=dict(act_pos, forcerange=[v_*units.torques for v_ in act_pos['forcerange']]),
+                                  vel_limits=dict(act_vel, ctrlrange=[v_*units.angular_velocity for v_ in act_vel['ctrlrange']],
+                                                  forcerange=[v_*units.torques for v_ in act_vel['forcerange']]))
     m = b.compile()
     # keyframe "initial" (:744-788): joint initial positions / velocities, spawn velocity
     for jo in joint_opts.values():
@@ -185,7 +218,8 @@ def setup_model(simulation_options, animat_options, arena_options=None, **kwargs
     mujoco_kw = dict(getattr(animat_options, 'mujoco', {}) or {})
     return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options,
                      fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane, plane=plane,
-                     **{k: v for k, v in mujoco_kw.items() if k in ('solref', 'solimp', 'friction')}, **kwargs)
+                     **{k: v for k, v in mujoco_kw.items()
+                        if k in ('solref', 'solimp', 'friction') or k.startswith(('act_pos_', 'act_vel_'))}, **kwargs)
 
 
 def model2mjcf_xml(m: Model) -> str:

@@ -36,18 +36,36 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     sensor_maps['datalinks2xfrc'] = links_body
     sensor_maps['data2xfrc'] = np.array([m.body_names.index(n) for n in sensor_data.xfrc.names], np.int32)
     physics.set_readout_maps(links_body, joints_jnt)
-    # Contacts (reference physics.py:360-382): pairs (body, '') -> every geom of that body keys (geom, -1)
+    # Contacts (reference physics.py:360-382): a sensor named (body, '') takes every geom of that body as key
+    # (geom, -1); a sensor named (body1, body2) takes every ordered geom pair (geom of body1, geom of body2)
     contacts_pairs = list(sensor_data.contacts.names)
-    geom_sensor = -np.ones(max(m.ngeom, 1), np.int32)
-    geompair2data = {}
-    for g in range(m.ngeom):
-        key = (m.body_names[m.geom_bodyid[g]], '')
-        if key in contacts_pairs:
-            geom_sensor[g] = contacts_pairs.index(key)
-            geompair2data[(g, -1)] = contacts_pairs.index(key)
+    body_names = m.body_names
+    geompair2data = {
+        (geom_id, -1): contacts_pairs.index((body_names[body_id], ''))
+        for geom_id, body_id in enumerate(m.geom_bodyid[:m.ngeom])
+        if (body_names[body_id], '') in contacts_pairs
+    }
+    if any(pair[1] != '' for pair in contacts_pairs if not isinstance(pair, str) and len(pair) == 2):
+        geompair2data.update({
+            (geom_id1, geom_id2): contacts_pairs.index((body_names[body_id1], body_names[body_id2]))
+            for geom_id1, body_id1 in enumerate(m.geom_bodyid[:m.ngeom])
+            for geom_id2, body_id2 in enumerate(m.geom_bodyid[:m.ngeom])
+            if (body_names[body_id1], body_names[body_id2]) in contacts_pairs
+        })
     sensor_maps['geompair2data'] = geompair2data
+    geompair2data_values = geompair2data.values()
+    for pair_i, pair in enumerate(contacts_pairs):
+        assert not isinstance(pair, str) and len(pair) == 2, f'Contact "{pair}" should be a pair of strings'
+        assert pair_i in geompair2data_values, f'Missing pair: {pair} ({body_names=})'
     if contacts_pairs:
-        physics.set_contact_maps(len(contacts_pairs), geom_sensor)
+        geom_sensor = -np.ones(max(m.ngeom, 1), np.int32)
+        pairs = []
+        for (g1, g2), row in geompair2data.items():
+            if g2 < 0:
+                geom_sensor[g1] = row
+            else:
+                pairs.append((g1, g2, row))
+        physics.set_contact_maps(len(contacts_pairs), geom_sensor, pairs)
     return sensor_maps
 
 

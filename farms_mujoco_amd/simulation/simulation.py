@@ -34,6 +34,8 @@ class Simulation:
 
     def __init__(self, mjcf_model: Model, base_link: str, simulation_options: SimulationOptions,
                  legacy_step: bool = False, **kwargs):
+        from .mjcf import check_supported_options
+        check_supported_options(simulation_options)
         self._mjcf_model = mjcf_model
         self.options = simulation_options
         self.pause = not self.options.play
@@ -41,6 +43,9 @@ class Simulation:
         device = kwargs.pop('device', 'cuda:0')
         self.physics = BatchedPhysics(mjcf_model, n_envs, device)
         self.handle_exceptions = kwargs.pop('handle_exceptions', False)
+        # dm_control raises PhysicsError inside the offending step; here the device freezes the offending env at that
+        # step (include/fmj.h) and the host looks at the status words every `check_every` steps (one sync each)
+        self.check_every = int(kwargs.pop('check_every', 100))
         extract_sub_dict(kwargs, ('control_timestep', 'n_sub_steps', 'flat_observation'))
         self.task = ExperimentTask(base_link=base_link, n_iterations=self.options.n_iterations,
                                    timestep=self.options.timestep, units=self.options.units,
@@ -129,6 +134,7 @@ class Simulation:
             a.wave.amplitude, a.wave.phase_lag, a.wave.env_phase = (c.amplitude.data_ptr(), c.phase_lag.data_ptr(),
                                                                      c.env_phase.data_ptr())
             a.wave.frequency = c.frequency
+            a.ctrl_out = phys.data.ctrl.data_ptr()       # callbacks reading physics.data.ctrl see the last step's command
         _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
                                             ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
         task.iteration += n_steps
@@ -146,9 +152,12 @@ class Simulation:
                 chunk = chunk or task.buffer_size
                 while task.iteration < task.n_iterations:
                     self.step_fused(min(chunk, task.buffer_size))
+                    self.physics.check_invalid_state()      # per chunk: a bad env is already frozen on the device
             else:
                 for _ in range(task.sim_iterations - task.sim_iteration):
                     self._env_step()
+                    if self.check_every and task.sim_iteration % self.check_every == 0:
+                        self.physics.check_invalid_state()
             self.physics.check_invalid_state()
         except PhysicsError as err:
             pylog.error(traceback.format_exc())
@@ -166,6 +175,8 @@ class Simulation:
                 yield iteration
                 for _ in range(self.task.substeps):
                     self._env_step()
+                if self.check_every and (iteration + 1) % self.check_every == 0:
+                    self.physics.check_invalid_state()
             self.physics.check_invalid_state()
         except PhysicsError as err:
             if verbose:

@@ -64,6 +64,7 @@ class ExperimentTask:
         self._controller = kwargs.pop('controller', None)
         self.animat_options = kwargs.pop('animat_options', None)
         self.external_force: float = kwargs.pop('external_force', 0.2)
+        self._app = None
         self._restart: bool = kwargs.pop('restart', False)
         self._callbacks: List[TaskCallback] = kwargs.pop('callbacks', [])
         self._extras: Dict = {'hfield': kwargs.pop('hfield', None)}
@@ -81,6 +82,8 @@ class ExperimentTask:
     # ---- episode ---------------------------------------------------------------------------------
     def initialize_episode(self, physics):
         """Sets the state of the environment at the start of each episode (reference task.py:87-154)."""
+        if self._restart:                      # reference task.py:91-94
+            assert self._app is not None, 'Simulation can not be restarted without application interface'
         self.iteration = 0
         self.sim_iteration = 0
         self.initialize_maps(physics)
@@ -121,6 +124,30 @@ class ExperimentTask:
         self.maps['ctrl']['vel'] = torch.as_tensor([names.index(f'actuator_velocity_{j}') for j in jn[ControlType.VELOCITY]], device=dev)
         self.maps['ctrl']['trq'] = torch.as_tensor([names.index(f'actuator_torque_{j}') for j in jn[ControlType.TORQUE]], device=dev)
         self.maps['ctrl']['springref'] = {j: int(m.jnt_qposadr[m.joint_names.index(j)]) for j in m.hinge_joint_names()}
+        # actuator kind from its bias parameters (reference task.py:258-271, including its quirk that a position
+        # actuator with kp = 0 reads as 'trq': SURVEY Appendix C.10)
+        jntname2actid = {name: {} for name in m.joint_names}
+        for act_i in range(m.nu):
+            bias = m.actuator_bias[act_i]
+            act_type = 'pos' if bias[1] != 0 else 'vel' if bias[2] != 0 else 'trq'
+            jntname2actid[m.joint_names[int(m.actuator_jntid[act_i])]][act_type] = act_i
+        self.maps['ctrl']['jntname2actid'] = jntname2actid
+        # Actuator limits (reference task.py:273-286): motors that are not position-controlled get their position and
+        # velocity actuators switched off by a zero force range, rewritten in the model at run time
+        if self.animat_options is not None:
+            limited = np.array(m.actuator_forcelimited, np.int32).copy()
+            frange = np.array(m.actuator_forcerange, float).reshape(m.nu, 2).copy()
+            changed = False
+            for mtr_opts in self.animat_options.control.motors:
+                if 'position' not in mtr_opts.control_types:
+                    for act_type in ('pos', 'vel'):
+                        if act_type in jntname2actid.get(mtr_opts.joint_name, {}):
+                            a = jntname2actid[mtr_opts.joint_name][act_type]
+                            limited[a] = 1
+                            frange[a] = (0.0, 0.0)
+                            changed = True
+            if changed:
+                physics.set_actuator_forcerange(limited, frange)
 
     # ---- per step -----------------------------------------------------------------------------------
     def update_sensors(self, physics, links_only=False):
@@ -163,9 +190,15 @@ class ExperimentTask:
         if fullstep:
             self.iteration += 1
         assert self.iteration <= self.n_iterations
+        if self.iteration == self.n_iterations and self._app is not None and not self._restart:
+            self._app.close()                  # reference task.py:358-364 (a viewer; None in headless batch runs)
         if fullstep:
             for callback in self._callbacks:
                 callback.after_step(task=self, physics=physics)
+
+    def set_app(self, app):
+        """Simulation application (reference task.py:82-85); None in headless batch runs."""
+        self._app = app
 
     def get_reward(self, physics):
         reward = 0
@@ -183,6 +216,30 @@ class ExperimentTask:
         if self.iteration >= self.n_iterations:
             terminate = 1
         return terminate
+
+    def action_spec(self, physics):
+        """Action specifications (reference task.py:371-378)."""
+        specs = []
+        for callback in self._callbacks:
+            spec = callback.action_spec(task=self, physics=physics)
+            if spec is not None:
+                specs += spec
+        return specs
+
+    def step_spec(self, physics):
+        """Timestep specifications (reference task.py:382-385)."""
+        for callback in self._callbacks:
+            callback.step_spec(task=self, physics=physics)
+
+    def get_observation(self, physics):
+        """Environment observation (reference task.py:387-390)."""
+        for callback in self._callbacks:
+            callback.get_observation(task=self, physics=physics)
+
+    def observation_spec(self, physics):
+        """Observation specifications (reference task.py:410-412)."""
+        for callback in self._callbacks:
+            callback.observation_spec(task=self, physics=physics)
 
     # ---- fused fast path ------------------------------------------------------------------------------
     def fusable(self):

@@ -66,8 +66,8 @@ class SwimmingHandler:
         if self.sph:
             self.water._surface = 1e8                                                              # drag.pyx:386-387
         self.physics = physics
-        physics.set_swimming(self.links_indices, self.xfrc_indices, self.body_index, self.links_coefficients,
-                             self.masses, self.heights, self.densities)
+        physics.set_swimming(len(self.xfrc.names), self.links_indices, self.xfrc_indices, self.body_index,
+                             self.links_coefficients, self.masses, self.heights, self.densities)
 
     def swim_dict(self):
         """Arrays in the layout the oracle wrapper takes (tests only)."""
@@ -94,8 +94,25 @@ class SwimmingHandler:
         self.water.set_velocity(vx=velocity[0], vy=velocity[1], vz=velocity[2])
 
 
-def drag_forces(iteration, data_links, links_index, data_xfrc, xfrc_index, coefficients, z3, z4, water,
-                mass, height, density, gravity, use_buoyancy):
-    """Signature-compatible free function (reference drag.pyx:152-167).  A single-link call has no
-    batched equivalent; use :meth:`SwimmingHandler.step`, which processes every link of every env."""
-    raise NotImplementedError('drag_forces(single link) is not exposed; use SwimmingHandler.step (fmj_drag)')
+def drag_forces(iteration, data_links, links_index, data_xfrc, xfrc_index, coefficients, z3=None, z4=None, water=None,
+                mass=0.0, height=1.0, density=1000.0, gravity=-9.81, use_buoyancy=True):
+    """Drag swimming of ONE link (reference drag.pyx:152-268), for every env at once -> C-ABI ``fmj_drag_link``.
+
+    ``data_links`` / ``data_xfrc`` are the ``links`` / ``xfrc`` sensor arrays of an :class:`AnimatData`
+    (``[buffer_size, n_envs, n, width]`` device tensors), ``water`` a :class:`WaterProperties`; ``z3`` / ``z4`` are the
+    reference's scratch vectors and are ignored.  Returns a bool tensor ``[n_envs]``: the reference's return value
+    (False where the link is above the surface and its xfrc row was left untouched, drag.pyx:192-194)."""
+    links = data_links.array if hasattr(data_links, 'array') else data_links
+    xfrc = data_xfrc.array if hasattr(data_xfrc, 'array') else data_xfrc
+    lrow = links[iteration, :, links_index]           # [n_envs, 20] view, env stride = links.stride(1)
+    xrow = xfrc[iteration, :, xfrc_index]
+    n_envs = lrow.shape[0]
+    hydro = torch.zeros(n_envs, dtype=torch.int32, device=links.device)
+    co = np.ascontiguousarray(coefficients, np.float64).reshape(2, 3)
+    w = water.as_c(gravity=gravity, use_buoyancy=use_buoyancy)
+    lib = _lib.load()
+    _lib.check(lib.fmj_drag_link(n_envs, links.device.index or 0, lrow.data_ptr(), links.stride(1), xrow.data_ptr(),
+                                 xfrc.stride(1), co.ctypes.data_as(ctypes.POINTER(ctypes.c_double)), float(mass),
+                                 float(height), float(density), ctypes.byref(w), hydro.data_ptr(),
+                                 ctypes.c_void_p(torch.cuda.current_stream(links.device).cuda_stream)))
+    return hydro.bool()

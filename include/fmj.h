@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMJ_ABI_VERSION 1
+#define FMJ_ABI_VERSION 2
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -41,8 +41,12 @@ enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, 
 enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
- * reference simulation.py:157-161,176-179) */
+ * reference simulation.py:157-161,176-179).  An env whose status carries one of the BAD* bits is FROZEN: from the
+ * step that found the bad value on (and in every later launch until the caller clears the status word) its state is
+ * left at the last finite values, it is no longer integrated and none of its ring-buffer rows are written
+ * (SURVEY 5).  FMJ_WARN_CONTACTFULL only reports a truncated contact list and does not freeze. */
 enum { FMJ_WARN_BADQPOS = 1, FMJ_WARN_BADQVEL = 2, FMJ_WARN_BADQACC = 4, FMJ_WARN_CONTACTFULL = 8 };
+#define FMJ_WARN_FREEZE (FMJ_WARN_BADQPOS | FMJ_WARN_BADQVEL | FMJ_WARN_BADQACC)
 
 /* ---- AnimatData column convention ("sc" in farms_core; reference physics.py:427-523) ------
  * farms_core is not vendored in the reference, so the integers are defined HERE and nowhere
@@ -168,7 +172,8 @@ typedef struct fmj_data {
   /* constraint path: required when the model has joint limits or collision geoms, else may be NULL */
   float* qacc_warmstart;     /* [n_envs,nv] in/out: qacc of the previous step (PGS warm start)  */
   float* contact;            /* [n_envs,max_contacts,16] out: pos(3) frame(9: normal,t1,t2) force(3: normal,t1,t2
-                                in the contact frame, what mj_contactForce returns) geom id (as float)   */
+                                in the contact frame, what mj_contactForce returns) and one int32 (bit pattern in
+                                the float slot) = geom1 << 16 | geom2 (mjContact.geom1 / geom2)            */
   int32_t* ncon;             /* [n_envs] out: active contacts of the last forward pass              */
 } fmj_data;
 
@@ -220,13 +225,20 @@ int fmj_get_sensor_layout(const fmj_ctx* ctx, fmj_sensor_layout_t* out);
 int fmj_kernel_info(const fmj_ctx* ctx, int32_t* lds_bytes_per_env, int32_t* threads_per_env);
 
 /* ---- swimming links (SwimmingHandler.__init__, reference drag.pyx:333-387) ------------------
- * links_index / xfrc_index: row of each swimming link in links / xfrc arrays;
+ * n_xfrc_rows: rows per env of the xfrc array (len(data.sensors.xfrc.names); the env stride of every xfrc row
+ * address); links_index / xfrc_index: row of each swimming link in links / xfrc arrays (xfrc_index < n_xfrc_rows);
  * body_index: MuJoCo body id of each swimming link (datalinks2xfrc, physics.py:385-393);
  * coefficients [ns,2,3]; masses, heights, densities [ns]. HOST pointers, copied. */
-int fmj_set_swimming(fmj_ctx* ctx, int32_t ns, const int32_t* links_index,
+int fmj_set_swimming(fmj_ctx* ctx, int32_t ns, int32_t n_xfrc_rows, const int32_t* links_index,
                      const int32_t* xfrc_index, const int32_t* body_index,
                      const double* coefficients, const double* masses,
                      const double* heights, const double* densities);
+
+/* Run-time rewrite of the actuator force limits: what ExperimentTask.initialize_control does to
+ * physics.named.model.actuator_forcelimited / actuator_forcerange (reference task.py:253-286: position and velocity
+ * actuators of motors that are not position-controlled get forcerange = [0, 0]).  forcelimited [nu], forcerange
+ * [nu,2]: HOST pointers, copied; the device tables are refreshed before the next launch. */
+int fmj_set_actuator_forcerange(fmj_ctx* ctx, int32_t nu, const int32_t* forcelimited, const double* forcerange);
 
 /* link / joint readout maps (get_physics2data_maps, reference physics.py:188-393):
  * link row i <- body links_body[i]; joint row j <- joint joints_jnt[j]. HOST pointers. */
@@ -245,6 +257,13 @@ int fmj_step(fmj_ctx* ctx, const fmj_data* d, int32_t n_steps, int64_t ctrl_step
  * physics.reset(keyframe_id=0) (reference task.py:137): mj_forward with actuation disabled. */
 int fmj_forward(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, void* hip_stream);
 
+/* Diagnostic twin of fmj_forward (parity tests of the intermediate stages): additionally stores, per env, the rows of
+ * H = M + diag(armature + timestep * damping) as the step assembles them - H_rows [n_envs, nv, *row_stride] DEVICE,
+ * row i holds H[i][j] at column depth(j) for the dofs j on the chain root -> i - and qfrc_smooth [n_envs, nv] =
+ * passive - bias + actuation + J' xfrc_applied.  Not on the product path. */
+int fmj_forward_debug(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, float* H_rows, int32_t* row_stride,
+                      float* qfrc_smooth, void* hip_stream);
+
 /* SwimmingHandler.step(iteration) (reference drag.pyx:389-411 -> drag_forces :152-268) for
  * every env: reads rows->links, writes rows->xfrc (rows of links above the surface are left
  * untouched, drag.pyx:192-194).  If xfrc_applied != NULL also performs the glue the reference
@@ -253,6 +272,14 @@ int fmj_forward(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, void
 int fmj_drag(fmj_ctx* ctx, const fmj_rows* rows, const fmj_water* water,
              const fmj_units* units, float* xfrc_applied, void* hip_stream);
 
+/* drag_forces(iteration, data_links, links_index, data_xfrc, xfrc_index, coefficients, z3, z4, water, mass, height,
+ * density, gravity, use_buoyancy) (reference drag.pyx:152-268) for ONE link in every env, no context needed:
+ * links_row / xfrc_row point at that link's row of env 0, *_env_stride = elements between envs.  Returns through
+ * hydrodynamics_out [n_envs] (DEVICE int32, may be NULL) what the reference returns (1 = the link is in the water). */
+int fmj_drag_link(int32_t n_envs, int32_t device, const float* links_row, int64_t links_env_stride, float* xfrc_row,
+                  int64_t xfrc_env_stride, const double* coefficients /* [2,3] */, double mass, double height,
+                  double density, const fmj_water* water, int32_t* hydrodynamics_out, void* hip_stream);
+
 /* physics2data(physics, iteration, data, maps, units, links_only) (reference
  * physics.py:527-545): mjData fields -> AnimatData rows with unit scaling. */
 int fmj_physics2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows,
@@ -260,7 +287,9 @@ int fmj_physics2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows,
 
 /* Contact sensors: map of collision geoms / geom pairs to AnimatData contact rows
  * (geompair2data, reference physics.py:360-382).  geom_sensor[g] = row of key (g, -1) or -1;
- * pairs = n_pairs x (geom1, geom2, row).  HOST pointers, copied. */
+ * pairs = n_pairs x (geom_a, geom_b, row) = the keys (geom_a, geom_b) of geompair2data.  A contact (geom1, geom2)
+ * is added to the rows of the keys (geom1, geom2) and (geom1, -1) with sign -1 and to those of (geom2, geom1) and
+ * (geom2, -1) with sign +1 (reference sensors.pyx:163-169).  HOST pointers, copied. */
 int fmj_set_contact_maps(fmj_ctx* ctx, int32_t n_contact_sensors, const int32_t* geom_sensor,
                          int32_t n_pairs, const int32_t* pairs);
 
@@ -298,6 +327,8 @@ typedef struct fmj_fused_args {
   fmj_water water;
   fmj_units units;
   fmj_wave_controller wave;
+  float* ctrl_out;          /* [n_envs,nu] DEVICE or NULL: with controller 1, receives the ctrl of the LAST step of the
+                               launch (what physics.data.ctrl holds after task.py:288-346 ran for that iteration) */
 } fmj_fused_args;
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);

@@ -15,7 +15,8 @@
  * The parts the reference OWNS are restated line by line:
  *   drag            <- reference farms_mujoco/swimming/drag.pyx:12-268
  *   physics2data    <- reference farms_mujoco/simulation/physics.py:449-524
- *   contacts2data   <- reference farms_mujoco/sensors/sensors.pyx:20-190
+ *   contacts2data   <- reference farms_mujoco/sensors/sensors.pyx:20-190 (fmjo_contacts2data; mj_contactForce restated
+ *                      for the pyramidal cone)
  *
  * Conventions: spatial vectors are [rot(3); lin(3)]; all c* quantities are expressed in world
  * axes about subtree_com[body_rootid]; quaternions w,x,y,z except AnimatData rows (x,y,z,w).
@@ -123,6 +124,7 @@ typedef struct ws_t {
   int *con_geom, *con_plane; double *con_pos, *con_frame, *con_dist, *con_mu; int *con_efc;
   double *jointlimitfrc;
   double meaninertia;
+  int disable_actuation;      /* mj_forward with mjDSBL_ACTUATION (what dm_control runs after physics.reset, task.py:137) */
 } ws_t;
 
 enum { EFC_LIMIT = 0, EFC_CONTACT = 1 };
@@ -400,6 +402,7 @@ static void actuation(const fmj_model* m, ws_t* w, const double* qpos, const dou
     const double* b = m->actuator_bias + 3 * a;
     double f = m->actuator_gain[a] * c + b[0] + b[1] * len + b[2] * vel;
     if (m->actuator_forcelimited[a]) f = fmin(fmax(f, m->actuator_forcerange[2 * a]), m->actuator_forcerange[2 * a + 1]);
+    if (w->disable_actuation) f = 0.0;
     w->actuator_force[a] = f;
     w->qfrc_actuator[m->jnt_dofadr[j]] += f;
   }
@@ -970,6 +973,82 @@ int fmjo_physics2data(const fmj_model* m, int n_envs, const double* qpos, const 
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* contacts: mj_contactForce (pyramidal, condim 3) + cycontacts2data (reference sensors.pyx:20-190) */
+
+#define FMJO_CONTACT_W 18   /* pos(3) frame(9) force(3: normal,t1,t2) geom1 geom2 dist */
+
+/* the contact list of the last forward pass as records of FMJO_CONTACT_W doubles (mjContact + mj_contactForce).
+ * geom1 = the plane, geom2 = the animat geom: MuJoCo orders a pair by geom type and the plane has the lowest. */
+static void export_contacts(const ws_t* w, double* out) {
+  for (int c = 0; c < w->ncon; c++) {
+    double* o = out + (size_t)FMJO_CONTACT_W * c;
+    memcpy(o, w->con_pos + 3 * c, 3 * sizeof(double)); memcpy(o + 3, w->con_frame + 9 * c, 9 * sizeof(double));
+    const double* f = w->efc_force + w->con_efc[c];      /* pyramid edge forces -> contact-frame force */
+    double mu = w->con_mu[c];
+    o[12] = f[0] + f[1] + f[2] + f[3]; o[13] = mu * (f[0] - f[1]); o[14] = mu * (f[2] - f[3]);
+    o[15] = w->con_plane[c]; o[16] = w->con_geom[c]; o[17] = w->con_dist[c];
+  }
+}
+
+/* geompair2data lookup: keys = n_keys x (geom_a, geom_b or -1, row); -1 if the key is absent */
+static int key_row(int n_keys, const int32_t* keys, int a, int b) {
+  for (int k = 0; k < n_keys; k++) if (keys[3 * k] == a && keys[3 * k + 1] == b) return keys[3 * k + 2];
+  return -1;
+}
+
+/* store_forces (sensors.pyx:20-52) */
+static double store_forces(double* row, const double* forcetorque, const double* frame, const double* pos, int sign) {
+  double reaction[3], friction[3], total[3];
+  for (int i = 0; i < 3; i++) {
+    reaction[i] = sign * forcetorque[0] * frame[0 + i];                                       /* :34 */
+    double friction1 = sign * forcetorque[1] * frame[3 + i], friction2 = sign * forcetorque[2] * frame[6 + i];   /* :35-36 */
+    friction[i] = friction1 + friction2;                                                       /* :37 */
+    total[i] = reaction[i] + friction[i];                                                      /* :38 */
+  }
+  for (int i = 0; i < 3; i++) {                                                                /* :39-47 */
+    row[FMJ_CONTACT_REACTION + i] += reaction[i]; row[FMJ_CONTACT_FRICTION + i] += friction[i]; row[FMJ_CONTACT_TOTAL + i] += total[i];
+  }
+  double norm = sqrt(total[0] * total[0] + total[1] * total[1] + total[2] * total[2]);         /* :48 */
+  for (int i = 0; i < 3; i++) row[FMJ_CONTACT_POSITION + i] += norm * pos[i];                  /* :49-51 */
+  return norm;
+}
+
+/* cycontacts2data (sensors.pyx:140-190) for one env; rows [n_rows][12] are zeroed first (the reference adds into a
+ * fresh ring-buffer row) */
+static void contacts2data_one(int ncon, const double* con, int n_rows, int n_keys, const int32_t* keys,
+                              double meters, double newtons, double* rows) {
+  double* norm_sum = dalloc(n_rows);
+  memset(rows, 0, (size_t)n_rows * FMJ_CONTACT_SIZE * sizeof(double));
+  for (int c = 0; c < ncon; c++) {
+    const double* ct = con + (size_t)FMJO_CONTACT_W * c;
+    int geom1 = (int)ct[15], geom2 = (int)ct[16];
+    const int pair[4][2] = {{geom1, geom2}, {geom2, geom1}, {geom1, -1}, {geom2, -1}};       /* :163-168 */
+    const int sign[4] = {-1, +1, -1, +1};
+    for (int k = 0; k < 4; k++) {
+      int index = key_row(n_keys, keys, pair[k][0], pair[k][1]);                              /* :169-170 */
+      if (index < 0) continue;
+      norm_sum[index] += store_forces(rows + (size_t)index * FMJ_CONTACT_SIZE, ct + 12, ct + 3, ct, sign[k]);   /* :55-75 */
+    }
+  }
+  double imeters = 1.0 / meters, inewtons = 1.0 / newtons;                                     /* :122-123 */
+  for (int index = 0; index < n_rows; index++) {
+    double* r = rows + (size_t)index * FMJ_CONTACT_SIZE;
+    if (norm_sum[index] > 0) for (int i = 0; i < 3; i++) r[FMJ_CONTACT_POSITION + i] /= norm_sum[index];   /* :85-88 */
+    for (int i = 0; i < 9; i++) r[i] *= inewtons;                                              /* :99-107 */
+    for (int i = 0; i < 3; i++) r[FMJ_CONTACT_POSITION + i] *= imeters;                        /* :108-110 */
+  }
+  free(norm_sum);
+}
+
+int fmjo_contacts2data(int n_envs, int max_contacts, const double* contact, const int32_t* ncon, int n_rows, int n_keys,
+                       const int32_t* keys, double meters, double newtons, double* rows) {
+  for (int e = 0; e < n_envs; e++)
+    contacts2data_one(ncon[e], contact + (size_t)e * max_contacts * FMJO_CONTACT_W, n_rows, n_keys, keys, meters, newtons,
+                      rows + (size_t)e * n_rows * FMJ_CONTACT_SIZE);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* public: batched step                                                                         */
 
 typedef struct step_job {
@@ -1057,11 +1136,7 @@ int fmjo_forward_debug(const fmj_model* m, const double* qpos, const double* qve
   CP(sensordata, sd, nsensordata(m));
   if (ncon_nefc) { ncon_nefc[0] = w->ncon; ncon_nefc[1] = w->nefc; }
   CP(efc_force, w->efc_force, w->nefc);
-  if (contact_out) for (int c = 0; c < w->ncon; c++) {  /* [ncon, 3 pos + 9 frame + dist + geom] */
-    double* o = contact_out + 14 * c;
-    memcpy(o, w->con_pos + 3 * c, 3 * sizeof(double)); memcpy(o + 3, w->con_frame + 9 * c, 9 * sizeof(double));
-    o[12] = w->con_dist[c]; o[13] = w->con_geom[c];
-  }
+  if (contact_out) export_contacts(w, contact_out);   /* [ncon, FMJO_CONTACT_W] */
 #undef CP
   free(sd); ws_free(w);
   return FMJ_OK;
@@ -1084,6 +1159,8 @@ typedef struct fused_job {
   const double* units;  /* meters,newtons,torques,velocity,angular_velocity */
   const double *wave_amplitude, *wave_phase_lag, *wave_env_phase; double wave_frequency;
   double meaninertia;
+  int n_xfrc;                       /* rows per env of the xfrc array */
+  double* contacts; int n_contact_rows, n_keys; const int32_t* keys;   /* contact sensor rows [buffer, n_envs, n_rows, 12] or NULL */
 } fused_job;
 
 static void* fused_worker(void* arg) {
@@ -1093,6 +1170,7 @@ static void* fused_worker(void* arg) {
   double* ctrl = dalloc(m->nu);
   double* xa = dalloc(6 * nb);
   double* tmp_links = dalloc((size_t)J->n_links * FMJ_LINK_SIZE);
+  double* con = dalloc((size_t)(m->max_contacts > 0 ? m->max_contacts : 1) * FMJO_CONTACT_W);
   for (int e = J->e0; e < J->e1; e++) {
     double* qpos = J->qpos + (size_t)e * m->nq; double* qvel = J->qvel + (size_t)e * m->nv;
     double* xpos = J->xpos + (size_t)e * nb * 3; double* xquat = J->xquat + (size_t)e * nb * 4;
@@ -1100,9 +1178,19 @@ static void* fused_worker(void* arg) {
     memset(w->qacc_warmstart, 0, m->nv * sizeof(double));
     memset(xa, 0, 6 * nb * sizeof(double));
     int warn = 0;
+    if (J->contacts) {     /* contact list of the state the loop starts from: physics.reset's mj_forward, actuation off */
+      w->disable_actuation = 1;
+      forward(m, w, qpos, qvel, NULL, J->qpos_spring + (size_t)e * m->nq, NULL, NULL);
+      w->disable_actuation = 0;
+    }
     for (int s = 0; s < J->n_steps; s++) {
       int it = J->iteration0 + s, index = it % J->buffer_size;
       double* lrow = tmp_links;
+      if (J->contacts && J->do_readout) {   /* cycontacts2data on the contacts of the last forward pass (physics.py:543-545) */
+        export_contacts(w, con);
+        contacts2data_one(w->ncon, con, J->n_contact_rows, J->n_keys, J->keys, J->units[0], J->units[1],
+                          J->contacts + ((size_t)index * J->n_envs + e) * J->n_contact_rows * FMJ_CONTACT_SIZE);
+      }
       if (J->do_readout) {
         lrow = J->links + ((size_t)index * J->n_envs + e) * J->n_links * FMJ_LINK_SIZE;
         double* jrow = J->joints + ((size_t)index * J->n_envs + e) * J->n_joints * FMJ_JOINT_SIZE;
@@ -1112,8 +1200,8 @@ static void* fused_worker(void* arg) {
         physics2data_one(m, qpos, qvel, xpos, xquat, xipos, sd, J->n_links, J->links_body, 0, NULL, J->units, 1, lrow, NULL);
       }
       if (J->do_drag) {
-        double* xrow = J->xfrc + ((size_t)index * J->n_envs + e) * J->n_links * FMJ_XFRC_SIZE;
-        fmjo_drag(1, J->n_links, J->n_links, nb, J->ns, J->sw_links_index, J->sw_xfrc_index, J->sw_body_index,
+        double* xrow = J->xfrc + ((size_t)index * J->n_envs + e) * J->n_xfrc * FMJ_XFRC_SIZE;
+        fmjo_drag(1, J->n_links, J->n_xfrc, nb, J->ns, J->sw_links_index, J->sw_xfrc_index, J->sw_body_index,
                   J->coefficients, J->masses, J->heights, J->densities, J->surface, J->water_vel, J->viscosity,
                   J->gravity, J->use_buoyancy, J->units[1], J->units[2], lrow, xrow, xa);
       }
@@ -1130,7 +1218,7 @@ static void* fused_worker(void* arg) {
     }
     if (J->status) J->status[e] |= warn;
   }
-  free(ctrl); free(xa); free(tmp_links); ws_free(w);
+  free(ctrl); free(xa); free(tmp_links); free(con); ws_free(w);
   return NULL;
 }
 
@@ -1144,7 +1232,8 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
                    const double* coefficients, const double* masses, const double* heights, const double* densities,
                    double surface, const double* water_vel, double viscosity, double gravity, int use_buoyancy,
                    const double* units, const double* wave_amplitude, const double* wave_phase_lag,
-                   const double* wave_env_phase, double wave_frequency, int n_threads) {
+                   const double* wave_env_phase, double wave_frequency, int n_threads,
+                   int n_xfrc, double* contacts, int n_contact_rows, int n_keys, const int32_t* keys) {
   if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > n_envs) n_threads = n_envs;
@@ -1166,6 +1255,7 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
     J->viscosity = viscosity; J->gravity = gravity; J->use_buoyancy = use_buoyancy; J->units = units;
     J->wave_amplitude = wave_amplitude; J->wave_phase_lag = wave_phase_lag; J->wave_env_phase = wave_env_phase;
     J->wave_frequency = wave_frequency; J->meaninertia = mi;
+    J->n_xfrc = n_xfrc > 0 ? n_xfrc : n_links; J->contacts = contacts; J->n_contact_rows = n_contact_rows; J->n_keys = n_keys; J->keys = keys;
     if (n_threads == 1) fused_worker(J); else pthread_create(&th[t], NULL, fused_worker, J);
   }
   if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);

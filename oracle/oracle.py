@@ -15,6 +15,7 @@ _lib = None
 
 _D = ctypes.POINTER(ctypes.c_double)
 _I = ctypes.POINTER(ctypes.c_int32)
+CONTACT_W = 18      # oracle contact record: pos(3) frame(9) force(3: normal,t1,t2) geom1 geom2 dist
 
 
 def build(force=False):
@@ -87,7 +88,7 @@ def forward_debug(model, qpos, qvel, ctrl=None, qpos_spring=None, xfrc_applied=N
              qfrc_constraint=np.zeros(nv), qacc=np.zeros(nv), xpos=np.zeros((nb, 3)), xquat=np.zeros((nb, 4)),
              xipos=np.zeros((nb, 3)), subtree_com=np.zeros((nb, 3)), cvel=np.zeros((nb, 6)),
              sensordata=np.zeros(m.nsensordata), counts=np.zeros(2, np.int32), efc_force=np.zeros(max(maxefc, 1)),
-             contact=np.zeros((max(m.max_contacts, 1), 14)))
+             contact=np.zeros((max(m.max_contacts, 1), CONTACT_W)))
     rc = lib().fmjo_forward_debug(ctypes.byref(c), _d(qpos), _d(qvel), _d(ctrl), _d(qs), _d(xf), _d(o['M']),
                                   _d(o['qfrc_bias']), _d(o['qfrc_passive']), _d(o['qfrc_actuator']),
                                   _d(o['qfrc_xfrc']), _d(o['qfrc_smooth']), _d(o['qacc_smooth']),
@@ -137,11 +138,45 @@ def physics2data(model, qpos, qvel, xpos, xquat, xipos, sensordata, links_body, 
     return links, joints
 
 
+def geompair_keys(geompair2data):
+    """geompair2data dict {(geom_a, geom_b or -1): row} (reference physics.py:360-374) -> int32 [n_keys, 3]."""
+    k = np.array([(a, b, r) for (a, b), r in geompair2data.items()], np.int32).reshape(-1, 3)
+    return np.ascontiguousarray(k)
+
+
+def contacts2data(contact, ncon, geompair2data, n_rows, meters=1.0, newtons=1.0):
+    """cycontacts2data (reference sensors.pyx:140-190) on oracle contact records [n, max_contacts, CONTACT_W]."""
+    contact = _c64(contact); n, maxc = contact.shape[:2]
+    nc = np.ascontiguousarray(ncon, np.int32)
+    keys = geompair_keys(geompair2data)
+    rows = np.zeros((n, n_rows, 12))
+    f = lib().fmjo_contacts2data
+    f.restype = ctypes.c_int
+    f.argtypes = [ctypes.c_int, ctypes.c_int, _D, _I, ctypes.c_int, ctypes.c_int, _I, ctypes.c_double, ctypes.c_double, _D]
+    rc = f(n, maxc, _d(contact), _i(nc), int(n_rows), len(keys), _i(keys), float(meters), float(newtons), _d(rows))
+    assert rc == 0
+    return rows
+
+
+def contacts_from_hip(contact16):
+    """HIP contact records [.., 16] (pos, frame, force, int32 geom1 << 16 | geom2 in the last float slot) -> oracle
+    records [.., CONTACT_W] (dist unknown: 0)."""
+    c = np.asarray(contact16, np.float32)
+    gg = np.ascontiguousarray(c[..., 15]).view(np.int32)
+    out = np.zeros(c.shape[:-1] + (CONTACT_W,))
+    out[..., :15] = c[..., :15]
+    out[..., 15] = gg >> 16
+    out[..., 16] = gg & 0xffff
+    return out
+
+
 def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer_size=1, do_readout=True,
               do_drag=True, controller=0, ctrl=None, ctrl_step_stride=0, wave=None, links_body=None,
-              joints_jnt=None, units=(1.0, 1.0, 1.0, 1.0, 1.0), n_threads=1):
+              joints_jnt=None, units=(1.0, 1.0, 1.0, 1.0, 1.0), n_threads=1, n_xfrc=None, geompair2data=None,
+              n_contact_rows=0):
     """The fused loop (readout -> drag -> ctrl -> mj_step) x n_steps.  ``state`` = dict(qpos, qvel, xpos, xquat,
-    xipos, sensordata[, qpos_spring]) batch-first; returns new state + ring-buffer rows."""
+    xipos, sensordata[, qpos_spring]) batch-first; returns new state + ring-buffer rows.  ``n_xfrc`` = rows per env of
+    the xfrc array (default: one per link row); ``geompair2data`` + ``n_contact_rows`` add the contact sensor rows."""
     m = model
     c = m.as_c()
     qpos = _c64(state['qpos']).reshape(-1, m.nq).copy(); n = qpos.shape[0]
@@ -154,7 +189,10 @@ def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer
     lb = np.ascontiguousarray(np.arange(1, m.nbody) if links_body is None else links_body, np.int32)
     jj = np.ascontiguousarray(np.nonzero(m.jnt_type != 0)[0] if joints_jnt is None else joints_jnt, np.int32)
     links = np.zeros((buffer_size, n, len(lb), 20)); joints = np.zeros((buffer_size, n, len(jj), 12))
-    xfrc = np.zeros((buffer_size, n, len(lb), 6))
+    n_xfrc = len(lb) if n_xfrc is None else int(n_xfrc)
+    xfrc = np.zeros((buffer_size, n, n_xfrc, 6))
+    keys = geompair_keys(geompair2data) if geompair2data else None
+    contacts = np.zeros((buffer_size, n, n_contact_rows, 12)) if geompair2data else None
     if swim is not None:
         li, xi, bi, co, ma, he, de = _swim_arrays(swim)
     else:
@@ -176,10 +214,11 @@ def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer
                               _i(xi), _i(bi), _d(co), _d(ma), _d(he), _d(de), ctypes.c_double(water['surface']), _d(wv),
                               ctypes.c_double(water['viscosity']), ctypes.c_double(water.get('gravity', -9.81)),
                               int(water['use_buoyancy']), _d(u), _d(wa), _d(wp), _d(we), ctypes.c_double(wf),
-                              int(n_threads))
+                              int(n_threads), n_xfrc, _d(contacts), int(n_contact_rows), 0 if keys is None else len(keys),
+                              _i(keys))
     assert rc == 0, rc
     return dict(qpos=qpos, qvel=qvel, xpos=xpos, xquat=xquat, xipos=xipos, sensordata=sd, status=status,
-                links=links, joints=joints, xfrc=xfrc)
+                links=links, joints=joints, xfrc=xfrc, contacts=contacts)
 
 
 class _CpgDesc(ctypes.Structure):

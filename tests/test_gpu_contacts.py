@@ -159,32 +159,10 @@ def test_walking_rollout(oracle):
     assert float(d.qpos[:, 2].min()) > 0.0 and float(d.qpos[:, 2].max()) < 0.1      # the plane holds the animal up
 
 
-def _contacts2data_numpy(contact, ncon, geom_sensor, n_rows, meters, newtons):
-    """reference sensors.pyx:20-190 in plain Python loops (small cases only)."""
-    out = np.zeros((n_rows, 12)); norm_sum = np.zeros(n_rows)
-    for c in range(ncon):
-        ct = contact[c]
-        g2 = int(np.float32(ct[15]).view(np.int32))
-        for key_row, sign in ((geom_sensor[g2], +1),):          # (geom2, -1) -> +1 (sensors.pyx:167)
-            if key_row < 0:
-                continue
-            frame = ct[3:12]; ft = ct[12:15]
-            reaction = sign*ft[0]*frame[0:3]
-            friction = sign*ft[1]*frame[3:6] + sign*ft[2]*frame[6:9]
-            total = reaction + friction
-            out[key_row, 0:3] += reaction; out[key_row, 3:6] += friction; out[key_row, 6:9] += total
-            nrm = np.linalg.norm(total)
-            out[key_row, 9:12] += nrm*ct[0:3]; norm_sum[key_row] += nrm
-    for r in range(n_rows):
-        if norm_sum[r] > 0:
-            out[r, 9:12] /= norm_sum[r]
-    out[:, :9] /= newtons; out[:, 9:] /= meters
-    return out
-
-
 def test_contacts2data_rows(oracle):
-    """cycontacts2data through the task/readout layer: rows equal the reference algorithm applied to the same
-    contact list, units scaled, force-weighted contact position."""
+    """cycontacts2data through the task/readout layer: rows equal the C restatement of reference sensors.pyx:20-190
+    (oracle/fmj_oracle.c: fmjo_contacts2data) applied to the same contact list, units scaled, force-weighted contact
+    position."""
     import torch
     from farms_mujoco_amd.data import AnimatData
     from farms_mujoco_amd.physics import BatchedPhysics
@@ -205,17 +183,115 @@ def test_contacts2data_rows(oracle):
     torch.cuda.synchronize()
     ncon = phys.data.ncon.cpu().numpy(); contact = phys.data.contact.cpu().numpy()
     assert ncon.min() >= 1
-    geom_sensor = -np.ones(m.ngeom, int)
-    for g in range(m.ngeom):
-        key = (m.body_names[m.geom_bodyid[g]], '')
-        if key in pairs:
-            geom_sensor[g] = pairs.index(key)
+    con = oracle.contacts_from_hip(contact)
+    plane = int(np.nonzero(m.geom_type == 0)[0][0])
+    assert np.all(con[0, :ncon[0], 15] == plane) and np.all(m.geom_bodyid[con[0, :ncon[0], 16].astype(int)] > 0)
+    want = oracle.contacts2data(con, ncon, maps['sensors']['geompair2data'], len(pairs), units.meters, units.newtons)
     got = data.sensors.contacts.array[1].cpu().numpy()
-    for e in range(n):
-        want = _contacts2data_numpy(contact[e].astype(np.float64), ncon[e], geom_sensor, len(pairs), units.meters, units.newtons)
-        assert np.allclose(got[e], want, rtol=1e-5, atol=1e-7)
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-7)
     assert np.abs(got[..., 2]).max() > 0            # some vertical reaction force was logged
     assert float(data.sensors.contacts.array[0].abs().max()) == 0.0
+
+
+def test_contact_pair_sensors_and_signs(oracle):
+    """The four keys of reference sensors.pyx:163-169 on plane contacts (geom1 = the arena plane on the world body,
+    geom2 = the link geom): a (link, '') sensor and a (link, 'world') body-pair sensor read the force ON the link
+    (sign +1), a ('world', link) pair sensor and the ('world', '') sensor read its reaction (sign -1); the body-pair
+    keys are every ordered geom pair of the two bodies (reference physics.py:367-374)."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from farms_mujoco_amd.simulation.physics import get_sensor_maps, get_physics2data_maps, physics2data
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    m = _walker(spawn_z=0.03)
+    n = 6
+    phys = BatchedPhysics(m, n)
+    rng = np.random.default_rng(4)
+    qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.1, 0.1, (n, m.nq - 7))
+    _set(phys, qpos, 0.02*rng.normal(size=(n, m.nv)))
+    phys.step(40)
+    foot, trunk = 'leg_front_L_3', 'body_5'
+    pairs = [(foot, ''), (foot, 'world'), ('world', foot), ('world', ''), (trunk, ''), ('world', trunk)]
+    data = AnimatData(m.timestep, 1, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    units = SimulationUnitScaling()
+    maps = {'sensors': get_sensor_maps(phys)}
+    get_physics2data_maps(phys, data.sensors, maps['sensors'])
+    g2d = maps['sensors']['geompair2data']
+    plane = int(np.nonzero(m.geom_type == 0)[0][0])
+    gfoot = [g for g in range(m.ngeom) if m.body_names[m.geom_bodyid[g]] == foot]
+    assert g2d[(gfoot[0], plane)] == 1 and g2d[(plane, gfoot[0])] == 2 and g2d[(gfoot[0], -1)] == 0 and g2d[(plane, -1)] == 3
+    physics2data(phys, 0, data, maps, units)
+    torch.cuda.synchronize()
+    got = data.sensors.contacts.array[0].cpu().numpy().astype(np.float64)
+    ncon = phys.data.ncon.cpu().numpy(); con = oracle.contacts_from_hip(phys.data.contact.cpu().numpy())
+    want = oracle.contacts2data(con, ncon, g2d, len(pairs))
+    assert np.allclose(got, want, rtol=1e-5, atol=1e-7)
+    on_floor = np.abs(got[:, 0, 2]) > 1e-4
+    assert on_floor.any()
+    assert np.array_equal(got[:, 0], got[:, 1])                              # (foot, '') == (foot, 'world')
+    assert np.allclose(got[on_floor, 2, :9], -got[on_floor, 0, :9], rtol=1e-6, atol=0)         # ('world', foot): the reaction
+    assert np.allclose(got[on_floor, 2, 9:], got[on_floor, 0, 9:], rtol=1e-6, atol=1e-9)       # same contact point
+    assert np.all(got[on_floor, 0, 2] > 0) and np.all(got[on_floor, 3, 2] < 0)                 # the floor pushes the foot up
+    # ('world', '') collects minus the sum of what every geom-only sensor would read
+    every = [(b, '') for b in m.body_names[1:] if any(m.geom_bodyid[g] == m.body_names.index(b) for g in range(m.ngeom))]
+    data2 = AnimatData(m.timestep, 1, n, m.body_names[1:], m.hinge_joint_names(), contacts=every)
+    maps2 = {'sensors': get_sensor_maps(phys)}
+    get_physics2data_maps(phys, data2.sensors, maps2['sensors'])
+    physics2data(phys, 0, data2, maps2, units)
+    torch.cuda.synchronize()
+    total = data2.sensors.contacts.array[0].cpu().numpy().astype(np.float64)[..., 6:9].sum(1)
+    assert np.allclose(got[:, 3, 6:9], -total, rtol=1e-5, atol=1e-6)
+    # a body pair that never touches the listed partner, and a missing pair, are refused like the reference does
+    with pytest.raises(AssertionError):
+        bad = AnimatData(m.timestep, 1, n, m.body_names[1:], m.hinge_joint_names(), contacts=[('no_such_body', '')])
+        get_physics2data_maps(phys, bad.sensors, {'sensors': {}}['sensors'])
+    with pytest.raises(AssertionError):
+        bad = AnimatData(m.timestep, 1, n, m.body_names[1:], m.hinge_joint_names(), contacts=['body_0'])
+        get_physics2data_maps(phys, bad.sensors, {})
+
+
+def test_fused_walk_contact_rows_vs_oracle(oracle):
+    """Config 4 end to end against the oracle alone: the fused HIP loop (collision -> PGS -> contact forces ->
+    cycontacts2data rows, with geom-only and body-pair sensors) versus the fp64 restatement doing the same from the same
+    inputs: mj_step, mj_contactForce and sensors.pyx:140-190, none of it fed from the HIP contact list."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    m = _walker()
+    n, T = 8, 40
+    pairs = [(b, '') for b in m.body_names[1:] if b.endswith('_3')] + [('world', 'body_0'), ('body_11', 'world'), ('world', '')]
+    data = AnimatData(m.timestep, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    sim = Simulation(m, m.body_names[1], SimulationOptions(timestep=m.timestep, n_iterations=T), n_envs=n, data=data, buffer_size=T)
+    sim.reset()
+    d = sim.physics.data
+    rng = np.random.default_rng(8)
+    q0 = np.tile(m.key_qpos, (n, 1)); q0[:, 7:] += rng.uniform(-0.15, 0.15, (n, m.nq - 7)); q0[:, 2] = 0.03 + 0.01*rng.uniform(size=n)
+    d.qpos[:] = torch.as_tensor(q0, dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    q32 = d.qpos.cpu().numpy().astype(np.float64); v32 = d.qvel.cpu().numpy().astype(np.float64)
+    st = dict(qpos=q32, qvel=v32)
+    fds = [oracle.forward_debug(m, q32[e], v32[e]) for e in range(n)]
+    for k in ('xpos', 'xquat', 'xipos'):
+        st[k] = np.array([fd[k] for fd in fds])
+    sd = np.array([fd['sensordata'] for fd in fds]); sd[:, 6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0
+    st['sensordata'] = sd
+    assert sim.task.fusable()
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    g2d = sim.task.maps['sensors']['geompair2data']
+    ref = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                           n_contact_rows=len(pairs), n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    rows = data.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
+    scale = np.abs(want[..., :9]).max()
+    err_f = np.abs(rows[..., :9] - want[..., :9]).max()/scale
+    loaded = np.linalg.norm(want[..., 6:9], axis=-1) > 0.05*scale
+    err_p = np.abs(rows[..., 9:] - want[..., 9:])[loaded].max()
+    print('contact rows vs oracle: force rel err', err_f, 'position abs err', err_p, 'peak force', scale)
+    assert err_f < 2e-2 and err_p < 1e-3 and scale > 0.05
+    assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3
+    assert _relerr(data.sensors.joints.array.cpu().numpy()[..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]]) < 2e-2
 
 
 def test_fused_walk_with_contact_rows(oracle):
@@ -342,3 +418,18 @@ def test_plane_box_contacts(oracle):
     ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=T)
     assert int(d.status.abs().sum()) == 0
     assert np.abs(d.qpos.cpu().numpy()[:, :3] - ref['qpos'][:, :3]).max() < 2e-3
+
+
+def test_create_refuses_more_rows_than_the_solver_holds(oracle):
+    """the HBM constraint path holds at most 192 rows per env (limited joints + 4 * max_contacts); a model
+    that could exceed that is refused at fmj_create instead of writing past its scratch rows."""
+    from farms_mujoco_amd import _lib
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _box_walker()                      # 2 limited joints
+    m.max_contacts = 47                    # 2 + 188 = 190 rows: accepted
+    phys = BatchedPhysics(m, 2)
+    phys.step(3)
+    assert int(phys.data.status.abs().sum()) == 0
+    m.max_contacts = 48                    # 2 + 192 = 194 rows: refused
+    with pytest.raises(_lib.FmjError, match='constraint rows'):
+        BatchedPhysics(m, 2)

@@ -43,31 +43,116 @@ def test_step_parity_other_morphologies(oracle, maker):
     assert err < 1e-4
 
 
-def test_mixed_batch_bucketed(oracle):
-    """Mixed-morphology batch = one fused simulation per morphology bucket, launched back to back on the same
-    stream; each bucket matches the oracle and is unaffected by the presence of the other."""
+def _bucket_sim(maker, n, T, ring, env_offset=0, seed=9, twins=()):
+    """One morphology bucket of the mixed batch: fused swimming with drag, wave controller, inputs keyed by global env
+    index."""
     import torch
     import farms_mujoco_amd.model as mm
     from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
     from farms_mujoco_amd.control import WaveController
     from farms_mujoco_amd.simulation.simulation import Simulation
+    m = getattr(mm, maker)()
+    qpos, qvel, psi = mm.synthetic_batch(m, n, seed=seed, env_offset=env_offset)
+    for e in twins:
+        qpos[e] = qpos[0]; qvel[e] = qvel[0]; psi[e] = psi[0]
+    sim = Simulation.from_sdf(SimulationOptions(timestep=m.timestep, n_iterations=T), AnimatOptions.from_model(m),
+                              ArenaOptions(water=WaterOptions(height=0.0)), model=m, n_envs=n,
+                              controller=WaveController(m, psi, frequency=1.5), buffer_size=ring)
+    sim.reset()
+    d = sim.physics.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    return sim, m
+
+
+def _bucket_oracle(oracle, sim, m, T, ring, envs):
+    """The oracle's fused loop on a sample of a bucket's envs, from the bucket's own fp32 inputs."""
+    d = sim.physics.data
+    q = d.qpos[envs].cpu().numpy().astype(np.float64); v = d.qvel[envs].cpu().numpy().astype(np.float64)
+    st = dict(qpos=q, qvel=v)
+    fds = [oracle.forward_debug(m, q[i], v[i]) for i in range(len(envs))]
+    for k in ('xpos', 'xquat', 'xipos'):
+        st[k] = np.array([fd[k] for fd in fds])
+    sd = np.array([fd['sensordata'] for fd in fds]); sd[:, 6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0
+    st['sensordata'] = sd
+    h = sim.task._callbacks[0].handler
+    c = sim.task._controller
+    water = dict(surface=h.water._surface, velocity=h.water._velocity, viscosity=h.water._viscosity, gravity=-9.81, use_buoyancy=h.buoyancy)
+    wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(), env_phase=c.env_phase[envs].cpu().numpy(),
+                frequency=c.frequency)
+    return oracle.run_fused(m, st, T, swim=h.swim_dict(), water=water, buffer_size=ring, controller=1, wave=wave, n_threads=8)
+
+
+def test_mixed_batch_bucketed(oracle):
+    """Mixed-morphology batch = one fused simulation per morphology bucket, launched back to back on the same
+    stream; each bucket matches the oracle (state and logged rows) and is unaffected by the presence of the other."""
+    import torch
     T = 40
-    sims = []
-    for maker, n in (('eel', 24), ('centipede', 8)):
-        m = getattr(mm, maker)()
-        _, _, psi = mm.synthetic_batch(m, n, seed=9)
-        sim = Simulation.from_sdf(SimulationOptions(timestep=m.timestep, n_iterations=T), AnimatOptions.from_model(m),
-                                  ArenaOptions(water=WaterOptions(height=0.0)), model=m, n_envs=n,
-                                  controller=WaveController(m, psi, frequency=1.5), buffer_size=T)
-        sim.reset()
-        sims.append((sim, m, psi))
-    for sim, _, _ in sims:
+    sims = [_bucket_sim(maker, n, T, T) for maker, n in (('eel', 24), ('centipede', 8))]
+    refs = [_bucket_oracle(oracle, sim, m, T, T, list(range(sim.physics.n_envs))) for sim, m in sims]
+    for sim, _ in sims:
         sim.run(fused=True)
     torch.cuda.synchronize()
-    for sim, m, psi in sims:
+    for (sim, m), ref in zip(sims, refs):
         assert int(sim.physics.data.status.abs().sum()) == 0
-        links = sim.task.data.sensors.links.array.cpu().numpy()
-        assert np.isfinite(links).all() and np.abs(links[-1, :, :, 14:17]).max() > 1e-3      # it swims
+        sens = sim.task.data.sensors
+        errs = dict(qpos=_relerr(sim.physics.data.qpos.cpu().numpy(), ref['qpos']), links=_relerr(sens.links.array.cpu().numpy(), ref['links']),
+                    xfrc=_relerr(sens.xfrc.array.cpu().numpy(), ref['xfrc']), joints=_relerr(sens.joints.array.cpu().numpy(), ref['joints']))
+        print(m.name, errs)
+        assert errs['qpos'] < 1e-4 and errs['links'] < 1e-4 and errs['xfrc'] < 2e-3 and errs['joints'] < 2e-3, (m.name, errs)
+        assert np.abs(sens.links.array.cpu().numpy()[-1, :, :, 14:17]).max() > 1e-3      # it swims
+    # a bucket run alone gives bitwise the same rows
+    alone, _ = _bucket_sim('eel', 24, T, T)
+    alone.run(fused=True)
+    torch.cuda.synchronize()
+    assert torch.equal(alone.task.data.sensors.links.array, sims[0][0].task.data.sensors.links.array)
+
+
+def test_full_size_config4_mixed_properties(oracle):
+    """BASELINE configs[4] at the per-GPU size bench.py runs (2048 eels + 2048 centipedes, fused with drag, 300 steps,
+    ring of 100): no warning bits; per bucket an 8-env sample matches the oracle (qpos, link rows, xfrc rows); envs with
+    identical inputs give identical rows wherever they sit in their bucket; the second half of each bucket run on its
+    own reproduces the full run bitwise (sharding invariance)."""
+    import torch
+    T, ring, N = 300, 100, 2048
+    for maker in ('eel', 'centipede'):
+        twins = [1, N//2 + 1, N - 1]
+        sim, m = _bucket_sim(maker, N, T, ring, twins=twins)
+        sample = [0, 2, 3, 777, 1024, 1500, 2046, 2047]
+        ref = _bucket_oracle(oracle, sim, m, T, ring, sample)
+        sim.run(fused=True)
+        torch.cuda.synchronize()
+        d = sim.physics.data
+        assert int(d.status.abs().sum()) == 0
+        q = d.qpos.cpu().numpy(); links = sim.task.data.sensors.links.array.cpu().numpy(); xfrc = sim.task.data.sensors.xfrc.array.cpu().numpy()
+        assert np.isfinite(q).all() and np.isfinite(links).all()
+        for e in twins:
+            assert np.array_equal(q[e], q[0]) and np.array_equal(links[:, e], links[:, 0])
+        errs = dict(qpos=_relerr(q[sample], ref['qpos']), links=_relerr(links[:, sample], ref['links']), xfrc=_relerr(xfrc[:, sample], ref['xfrc']))
+        print(maker, 'full-size sample vs oracle after', T, 'steps:', errs)
+        assert errs['qpos'] < 1e-4 and errs['links'] < 2e-4 and errs['xfrc'] < 2e-3, (maker, errs)
+        half = _half_run(maker, N, T, ring, twins)
+        assert np.array_equal(half.physics.data.qpos.cpu().numpy(), q[N//2:])
+        assert np.array_equal(half.task.data.sensors.links.array.cpu().numpy(), links[:, N//2:])
+        assert np.abs(q[:, 0] - sim.physics.model.key_qpos[0]).mean() > 0.005          # they swam
+
+
+def _half_run(maker, N, T, ring, twins):
+    """The second half [N/2, N) of a bucket as its own simulation, with the same per-env inputs as in the full batch."""
+    import torch
+    import farms_mujoco_amd.model as mm
+    m = getattr(mm, maker)()
+    qpos, qvel, psi = mm.synthetic_batch(m, N, seed=9)
+    for e in twins:
+        qpos[e] = qpos[0]; qvel[e] = qvel[0]; psi[e] = psi[0]
+    sim, _ = _bucket_sim(maker, N//2, T, ring, env_offset=N//2)
+    d = sim.physics.data
+    d.qpos[:] = torch.as_tensor(qpos[N//2:], dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel[N//2:], dtype=torch.float32)
+    sim.task._controller.env_phase[:] = torch.as_tensor(psi[N//2:], dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    return sim
 
 
 @pytest.mark.parametrize('n_envs', [1, 3])

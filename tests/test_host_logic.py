@@ -110,3 +110,92 @@ def test_animat_data_log_round_trip(tmp_path):
     for k in ('links', 'joints', 'xfrc', 'contacts'):
         assert torch.equal(getattr(back.sensors, k).array, getattr(d.sensors, k).array[:4])
     assert len(back.sensors.contacts.names) == 2
+
+
+class _StatusPhysics:
+    """Stands in for BatchedPhysics in the host-logic tests: counts steps, reports a bad env from step `bad_at` on."""
+    def __init__(self, bad_at=None):
+        self.steps, self.bad_at = 0, bad_at
+
+    def step(self, n=1):
+        self.steps += n
+
+    def check_invalid_state(self):
+        from farms_mujoco_amd.physics import PhysicsError
+        if self.bad_at is not None and self.steps >= self.bad_at:
+            raise PhysicsError('bad simulation state in 1 env(s); first env 0 status bits 2')
+
+
+def _host_sim(n_iterations=30, handle_exceptions=False, bad_at=None, check_every=5, substeps=1):
+    """Simulation with the device side stubbed out (constructor bypassed): sequencing and error policy only."""
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    sim = Simulation.__new__(Simulation)
+    sim.physics = _StatusPhysics(bad_at)
+    sim.handle_exceptions = handle_exceptions
+    sim.check_every = check_every
+    sim.task = _task(n_iterations=n_iterations, substeps=substeps)
+    sim._needs_reset = False
+    return sim
+
+
+def test_run_physics_error_policy():
+    """reference simulation.py:153-161: run() logs and re-raises PhysicsError, or returns when handle_exceptions."""
+    from farms_mujoco_amd.physics import PhysicsError
+    sim = _host_sim(bad_at=12)
+    with pytest.raises(PhysicsError):
+        sim.run(fused=False)
+    assert sim.physics.steps == 15 and sim.task.iteration == 15        # noticed at the first status look after step 12
+    sim = _host_sim(bad_at=12, handle_exceptions=True)
+    assert sim.run(fused=False) is None and sim.physics.steps == 15
+    ok = _host_sim()
+    ok.run(fused=False)
+    assert ok.physics.steps == 30 and ok.task.iteration == 30
+
+
+def test_iterator_physics_error_policy():
+    """reference simulation.py:164-179: iterator() yields the iteration before stepping it and always re-raises."""
+    from farms_mujoco_amd.physics import PhysicsError
+    sim = _host_sim(bad_at=7, handle_exceptions=True, substeps=2, n_iterations=10)
+    seen = []
+    with pytest.raises(PhysicsError):
+        for it in sim.iterator(show_progress=False, verbose=False):
+            seen.append(it)
+    assert seen == list(range(5)) and sim.physics.steps == 10           # 5 iterations x 2 sub-steps, checked every 5
+    ok = _host_sim(n_iterations=4)
+    assert list(ok.iterator()) == [0, 1, 2, 3] and ok.physics.steps == 4
+
+
+def test_unsupported_solver_options_are_refused():
+    """integrator / cone / solver other than Euler / pyramidal / PGS must not silently run different physics
+    (the reference forwards them to MuJoCo, mjcf.py:1342-1365)."""
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.mjcf import check_supported_options
+    check_supported_options(SimulationOptions())
+    check_supported_options(None)
+    for kw in (dict(solver='Newton'), dict(cone='elliptic'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='CG')):
+        with pytest.raises(NotImplementedError):
+            check_supported_options(SimulationOptions(**kw))
+
+
+def test_task_spec_hooks_and_restart_flag():
+    """reference task.py:371-412: the spec hooks fan out to the callbacks, action_spec concatenates what they return;
+    restart needs an application (task.py:91-94)."""
+    class Cb(TaskCallback):
+        def __init__(self): super().__init__(); self.calls = []
+        def action_spec(self, task, physics): self.calls.append('a'); return ['u']
+        def step_spec(self, task, physics): self.calls.append('s')
+        def get_observation(self, task, physics): self.calls.append('o')
+        def observation_spec(self, task, physics): self.calls.append('os')
+    a, b = Cb(), Cb()
+    t = _task(callbacks=[a, b])
+    assert t.action_spec(_FakePhysics()) == ['u', 'u']
+    t.step_spec(_FakePhysics()); t.get_observation(_FakePhysics()); t.observation_spec(_FakePhysics())
+    assert a.calls == b.calls == ['a', 's', 'o', 'os']
+    closed = []
+    t2 = _task(n_iterations=2)
+    t2.set_app(type('App', (), {'close': lambda self: closed.append(1)})())
+    for _ in range(2):
+        t2.before_step(None, _FakePhysics()); t2.after_step(_FakePhysics())
+    assert closed == [1]                                                  # task.py:358-364: the app is closed at the end
+    with pytest.raises(AssertionError):
+        ExperimentTask(base_link='b', n_iterations=1, timestep=1e-3, restart=True).initialize_episode(_FakePhysics())

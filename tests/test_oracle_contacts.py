@@ -26,7 +26,9 @@ def test_ball_rests_on_plane(oracle):
     assert fd['ncon'] == 1 and fd['nefc'] == 4
     assert abs(fd['efc_force'][:4].sum() - 0.5*9.81) < 1e-5
     assert np.allclose(fd['contact'][0, 3:6], [0, 0, 1])   # frame x-axis = plane normal
-    assert abs(fd['contact'][0, 12] + pen) < 1e-12         # dist = -penetration
+    assert abs(fd['contact'][0, 17] + pen) < 1e-12         # dist = -penetration
+    assert abs(fd['contact'][0, 12] - 0.5*9.81) < 1e-5 and np.allclose(fd['contact'][0, 13:15], 0, atol=1e-5)   # mj_contactForce: normal, t1, t2
+    assert fd['contact'][0, 15] == 0 and fd['contact'][0, 16] == 1      # geom1 = the plane (world geoms come first), geom2 = the ball
 
 
 def test_friction_holds_below_cone_and_slides_above(oracle):
@@ -98,7 +100,7 @@ def test_cylinder_and_box_contact_sets(oracle):
     fd = oracle.forward_debug(up, up.qpos0, np.zeros(6))
     assert fd['ncon'] == 3
     p = fd['contact'][:3, :3]
-    assert np.allclose(np.linalg.norm(p[:, :2], axis=1), r, atol=1e-12) and np.allclose(fd['contact'][:3, 12], -1e-3)
+    assert np.allclose(np.linalg.norm(p[:, :2], axis=1), r, atol=1e-12) and np.allclose(fd['contact'][:3, 17], -1e-3)
     ang = np.sort(np.arctan2(p[:, 1], p[:, 0]))
     assert np.allclose(np.diff(ang), 2*np.pi/3, atol=1e-9)
     c, s = np.cos(np.pi/4), np.sin(np.pi/4)
@@ -106,7 +108,7 @@ def test_cylinder_and_box_contact_sets(oracle):
     fd = oracle.forward_debug(lying, lying.qpos0, np.zeros(6))
     assert fd['ncon'] == 2
     assert np.allclose(np.sort(fd['contact'][:2, 0]), [-hh, hh], atol=1e-12) and np.allclose(fd['contact'][:2, 1], 0, atol=1e-12)
-    assert np.allclose(fd['contact'][:2, 12], -2e-3)
+    assert np.allclose(fd['contact'][:2, 17], -2e-3)
     box = _prism('box', (0.05, 0.03, 0.02), z=0.02 - 1e-3)
     fd = oracle.forward_debug(box, box.qpos0, np.zeros(6))
     assert fd['ncon'] == 4
@@ -116,3 +118,32 @@ def test_cylinder_and_box_contact_sets(oracle):
         fd = oracle.forward_debug(m, o['qpos'][0], o['qvel'][0])
         assert abs(fd['efc_force'][:fd['nefc']].sum() - 0.4*9.81) < 1e-3
         assert abs(o['qvel'][0]).max() < 1e-4
+
+
+def test_contacts2data_known_answers(oracle):
+    """cycontacts2data restated (reference sensors.pyx:20-190) on a hand-made contact list: the four keys and their
+    signs (:163-168), force decomposition along the contact frame (:33-47), force-weighted position (:48-51, :85-88),
+    unit scaling (:99-110), a contact that hits one row through two keys."""
+    W = oracle.CONTACT_W
+    con = np.zeros((1, 3, W))
+    f0 = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1.0])                      # frame rows: normal x, t1 y, t2 z
+    # contact 0: geoms (5, 7), force (2, 0.5, -0.25) at (1, 1, 1); contact 1: geoms (5, 8), force (4, 0, 0) at (3, 0, 0)
+    con[0, 0, :3] = (1, 1, 1); con[0, 0, 3:12] = f0; con[0, 0, 12:15] = (2, 0.5, -0.25); con[0, 0, 15:17] = (5, 7)
+    con[0, 1, :3] = (3, 0, 0); con[0, 1, 3:12] = f0; con[0, 1, 12:15] = (4, 0, 0); con[0, 1, 15:17] = (5, 8)
+    con[0, 2, 12:15] = (9, 9, 9); con[0, 2, 15:17] = (5, 7)             # beyond ncon: ignored
+    g2d = {(7, -1): 0, (5, -1): 1, (7, 5): 2, (5, 7): 3, (8, -1): 4, (8, 5): 4}
+    rows = oracle.contacts2data(con, [2], g2d, 5, meters=2.0, newtons=4.0)[0]
+    F0 = np.array([2, 0.5, -0.25]); F1 = np.array([4.0, 0, 0])
+    # row 0 = key (geom2 = 7, -1): +1 ; reaction along the normal, friction along the tangents
+    assert np.allclose(rows[0, 0:3], [2/4, 0, 0]) and np.allclose(rows[0, 3:6], [0, 0.5/4, -0.25/4]) and np.allclose(rows[0, 6:9], F0/4)
+    assert np.allclose(rows[0, 9:12], np.array([1, 1, 1])/2.0)
+    # row 1 = key (geom1 = 5, -1): -1, both contacts; position weighted by |total force|
+    assert np.allclose(rows[1, 6:9], -(F0 + F1)/4)
+    w0, w1 = np.linalg.norm(F0), np.linalg.norm(F1)
+    assert np.allclose(rows[1, 9:12], (w0*np.array([1, 1, 1]) + w1*np.array([3, 0, 0]))/(w0 + w1)/2.0)
+    assert np.allclose(rows[2], rows[0])                                # (geom2, geom1) = (7, 5): +1, same contact
+    assert np.allclose(rows[3, :9], -rows[0, :9]) and np.allclose(rows[3, 9:], rows[0, 9:])     # (geom1, geom2): -1
+    # row 4 is reached through (8, 5) and (8, -1): the contact is added twice, its position stays the contact point
+    assert np.allclose(rows[4, 6:9], 2*F1/4) and np.allclose(rows[4, 9:12], np.array([3, 0, 0])/2.0)
+    # no contacts: rows are zero (no division by the zero norm sum, sensors.pyx:85)
+    assert np.all(oracle.contacts2data(con, [0], g2d, 5) == 0.0)
