@@ -24,14 +24,27 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
 
 
-def algorithmic_bytes_per_env_step(m):
-    """B_full = B_core + B_log (fp32)."""
-    n_links = m.nbody - 1
-    n_joints = m.n_sensor_joints
-    ns = len(m.swimming)
-    b_core = 4*(m.nq + m.nv + m.nu) + 4*(m.nq + m.nv)
-    b_log = 4*(20*n_links + 4*n_joints + 6*ns)
-    return b_core + b_log
+def algorithmic_bytes_per_env_step(m, sim=None, workload='swim', sims=None):
+    """B_core = 4(nq+nv+nu) read + 4(nq+nv) written; B_log = 4(20 n_links + 4 n_joints + 6 n_s); config 4
+    adds 8 nv (warm start read + written) + 4*12 n_contact_sensors.  The mixed workload averages its buckets."""
+    def one(m_, sim_):
+        n_links = m_.nbody - 1
+        n_joints = m_.n_sensor_joints
+        ns = len(m_.swimming) if workload != 'walk' else 0
+        core = 4*(m_.nq + m_.nv + m_.nu) + 4*(m_.nq + m_.nv)
+        log = 4*(20*n_links + 4*n_joints + 6*ns)
+        cons = 0
+        if workload == 'walk':
+            n_cs = len(sim_.task.data.sensors.contacts.names) if sim_ is not None else 0
+            cons = 8*m_.nv + 4*12*n_cs
+        return core, log, cons
+    if workload == 'mixed' and sims:
+        parts = [(one(s_.physics.model, s_), s_.physics.n_envs) for s_ in sims]
+        tot = sum(n for _, n in parts)
+        core, log, cons = (sum(p[i]*n for p, n in parts)/tot for i in range(3))
+    else:
+        core, log, cons = one(m, sim)
+    return dict(core=core, log=log, cons=cons, full=core + log + cons)
 
 
 def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', morphology='salamander33'):
@@ -111,6 +124,20 @@ def cpu_baseline(m, sim, target_seconds=15.0):
                        f'(not MuJoCo), {cores} pthreads, {dt:.2f} s')
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (one per GPU, through
+    torch.distributed.run) before this process makes any GPU call, stream their output through, exit with their code."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -118,6 +145,8 @@ def main():
     ap.add_argument('--warmup', type=int, default=3000)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--chunk', type=int, default=100, help='steps per fused launch (= ring-buffer length)')
+    ap.add_argument('--min-seconds', type=float, default=0.25,
+                    help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed'],
                     help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede')
@@ -125,9 +154,11 @@ def main():
     ap.add_argument('--same-device', action='store_true', help='all ranks use cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(spawn_ranks(args))
     import torch
     import torch.distributed as dist
-    world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if args.same_device:
@@ -146,16 +177,18 @@ def main():
 
     n_envs = args.envs_per_gpu
     K, W = args.steps, args.warmup
-    chunk = max(1, min(args.chunk, K))
+    chunk = max(1, args.chunk)
+    n_it = 1 << 30                    # the task only needs iteration < n_iterations; the ring has `chunk` rows
     if args.workload == 'mixed':      # bucketed batching: half the envs are eels, half centipedes, no padding
-        sims = [build_sim(n_envs//2, K + W + chunk, chunk, rank*n_envs, device, morphology='eel')[0],
-                build_sim(n_envs - n_envs//2, K + W + chunk, chunk, rank*n_envs + n_envs//2, device, morphology='centipede')[0]]
+        sims = [build_sim(n_envs//2, n_it, chunk, rank*n_envs, device, morphology='eel')[0],
+                build_sim(n_envs - n_envs//2, n_it, chunk, rank*n_envs + n_envs//2, device, morphology='centipede')[0]]
         sim, m = sims[0], sims[0].physics.model
     else:
-        sim, m, _ = build_sim(n_envs, K + W + chunk, chunk, env_offset=rank*n_envs, device=device, workload=args.workload)
+        sim, m, _ = build_sim(n_envs, n_it, chunk, env_offset=rank*n_envs, device=device, workload=args.workload)
         sims = [sim]
 
     def run(n):
+        """n steps in launches of `chunk` (the last one shorter), a HIP event pair on the launch stream around each."""
         done, evs = 0, []
         while done < n:
             c = min(chunk, n - done)
@@ -168,13 +201,22 @@ def main():
             done += c
         return evs
 
-    run(W)
+    # warm-up; its event timings also size the timed region: the K-step block is repeated R times so that the region
+    # lasts >= --min-seconds (a single 20-step block is one 0.5 ms launch, which is not a measurement)
+    run(max(W, 1))
+    evw = run(chunk)                  # one more launch, warm, to size the timed region
     torch.cuda.synchronize()
+    est = evw[0][0].elapsed_time(evw[0][1])*1e-3/chunk
+    R = max(1, int(np.ceil(args.min_seconds/max(K*est, 1e-9)))) if args.min_seconds > 0 else 1
+    if world > 1:                                                   # every rank must time the same number of steps
+        t = torch.tensor([R], device=device if args.dist_backend == 'nccl' else 'cpu')
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        R = int(t.item())
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    evs = run(K)
+    evs = run(K*R)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -187,44 +229,56 @@ def main():
 
     if rank == 0:
         # dominant kernel = the fused step kernel; HIP events on the launch stream around every launch
-        full = [(e0.elapsed_time(e1)*1e-3, c) for e0, e1, c in evs if c == chunk]
-        avg_launch_s = float(np.mean([t for t, _ in full])) if full else float('nan')
-        b_step = algorithmic_bytes_per_env_step(m)
-        alg_bytes_per_launch = b_step*n_envs*chunk
+        full = np.array([e0.elapsed_time(e1)*1e-3 for e0, e1, c in evs if c == chunk] or [e0.elapsed_time(e1)*1e-3*chunk/c for e0, e1, c in evs])
+        avg_launch_s = float(full.mean())
+        b = algorithmic_bytes_per_env_step(m, sim, args.workload, sims)
+        alg_bytes_per_launch = b['full']*n_envs*chunk
         achieved = alg_bytes_per_launch/avg_launch_s/1e9
         info = sim.physics.kernel_info()
-        # HBM bytes per launch from the PMC passes (rocprofv3 cannot run inside this process): the committed
-        # summary of the same workload, profiles/latest_traffic.json, produced as DESIGN.md section 5 describes.
-        traffic = None
+        # HBM bytes and issue shares from the PMC passes (rocprofv3 cannot run inside this process): the committed summary
+        # of the same workload, per env-step, produced as DESIGN.md section 5 describes (scripts/pmc_summary.py)
+        traffic, binding, src = None, None, None
         try:
-            tr = json.load(open(os.path.join(ROOT, 'profiles', 'latest_traffic.json')))
-            if tr['steps_per_launch'] == chunk and tr['envs'] == n_envs and tr.get('workload', 'swim') == args.workload:
-                traffic = tr['fetch_bytes'] + tr['write_bytes']
+            for tr in json.load(open(os.path.join(ROOT, 'profiles', 'latest_traffic.json'))):
+                if tr['workload'] == args.workload and tr['envs'] == n_envs:
+                    traffic = (tr['fetch_bytes_per_env_step'] + tr['write_bytes_per_env_step'])*n_envs*chunk
+                    binding = tr.get('binding')
+                    src = tr.get('source')
         except Exception:
             pass
+        names = {'swim': 'salamander swim (~40 DoF)', 'walk': 'salamander walk on plane (PGS contacts)', 'mixed': 'eel + centipede swim (bucketed)'}
         out = {
-            'metric': 'env-steps/sec, salamander swim (~40 DoF) \u00d74096 envs, 1/2/4/8 MI355X',
-            'value': n_envs*world*K/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
-            'ms_per_step': dt/K*1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'metric': f'env-steps/sec, {names[args.workload]} \u00d7{n_envs} envs, 1/2/4/8 MI355X',
+            'value': n_envs*world*K*R/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
+            'repeats': R, 'steps_timed': K*R, 'timed_region_s': dt,
+            'ms_per_step': dt/(K*R)*1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic',
             'config': {'workload': {'swim': f'BASELINE configs[1]: {n_envs}x salamander-33 swimming per GPU (nbody={m.nbody}, '
                                             f'nv={m.nv}, nu={m.nu}), drag+buoyancy, no contact, h=1e-3, travelling-wave position '
-                                            f'control, sensor rows logged every step',
+                                            f'control, sensor rows logged every step; synthetic model per SURVEY Appendix D except limb '
+                                            f'kp 0.1 / inertia 1e-6 (Appendix D values are unstable at h=1e-3: DESIGN 3)',
                                     'walk': f'BASELINE configs[3]: {n_envs}x salamander-33 walking on a plane per GPU, joint limits + '
                                             f'sphere/capsule contacts, pyramidal cone, PGS <= 50 sweeps, link/joint/contact rows logged',
                                     'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
                                              f'GPU, one bucket per morphology'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',
                        'lds_bytes_per_env': info['lds_bytes_per_env']},
+            'launch_ms': {'n': int(full.size), 'min': float(full.min()*1e3), 'median': float(np.median(full)*1e3), 'max': float(full.max()*1e3)},
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
-                         'traffic_note': 'bytes per launch, FETCH_SIZE + WRITE_SIZE as counted (profiles/), algorithmic = '
-                                         f'{alg_bytes_per_launch}',
+                         'frac_log_only': b['log']*n_envs*chunk/avg_launch_s/1e9/HBM_PEAK_GBS,
+                         'traffic_note': 'HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
+                                         f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}',
                          'kernel': ('fmj_step_dual_kernel<true, MAXD> (two envs per wave)' if info['threads_per_env'] == 32
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,
-                         'algorithmic_bytes_per_env_step': b_step,
-                         'note': 'latency/VALU-issue-bound tree recursions (profiles/r01_v11_pmc_summary.txt): HBM is the nominal bound (SURVEY 8d)'},
+                         'algorithmic_bytes_per_env_step': b['full'],
+                         'algorithmic_bytes_note': f"B_full = B_core {b['core']} + B_log {b['log']}" + (f" + config-4 terms {b['cons']}" if b['cons'] else '')
+                                                   + '; B_core (state + ctrl) stays on chip between the steps of a fused launch, so '
+                                                     'frac_log_only counts the row payload alone (SURVEY 8d)',
+                         'binding': binding,
+                         'note': 'the step is bound by dependent-chain latency and VALU issue of the tree recursions, not by HBM '
+                                 '(binding: share of SQ_WAVE_CYCLES by SQ counter, profiles/): HBM is the nominal bound (SURVEY 8d)'},
         }
         if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:
