@@ -135,7 +135,8 @@ struct fmj_ctx {
   int device, n_envs;
   DevModel dm;
   std::vector<void*> allocs;
-  size_t lds_bytes, lds_bytes_dual;
+  size_t lds_bytes, lds_bytes_dual, lds_bytes_dual2;
+  int dual_gen;               // 2: fmj_dual2.inc (default), 1: fmj_dual.inc (FMJ_DUAL=1)
   fmj_sensor_layout_t layout;
   // host copies needed later
   std::vector<int> body_link_row, dof_joint_row, body_swim;
@@ -1412,6 +1413,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 }
 
 #include "fmj_dual.inc"
+#include "fmj_dual2.inc"
 
 // ---------------------------------------------------------------------------------------------
 // Build layout: this file is compiled once per register row length with -DFMJ_TU_MAXD=<4..32> (only the step-kernel
@@ -1421,6 +1423,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #define FMJ_CAT2(a, b) a##b
 #define FMJ_CAT(a, b) FMJ_CAT2(a, b)
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
+  if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD>;
   if (dual) return fused ? (void*)fmj_step_dual_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual_kernel<false, FMJ_TU_MAXD>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
@@ -1557,7 +1560,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, bool cons, bool dual) {
+static step_kernel_t tu_kernel(int rs, bool fused, bool cons, int dual) {
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1571,13 +1574,11 @@ static step_kernel_t tu_kernel(int rs, bool fused, bool cons, bool dual) {
   }
   return (step_kernel_t)k;
 }
-static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons != 0, false); }
-template <bool FUSED>
-static step_kernel_t pick_dual_kernel(int rs) { return tu_kernel(rs, FUSED, false, true); }
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons != 0, 0); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
-  if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = fused ? pick_dual_kernel<true>(c->dm.rs) : pick_dual_kernel<false>(c->dm.rs);
-    hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
+  if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc / fmj_dual.inc); fmj_forward keeps the single-env kernel
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, false, c->dual_gen);
+    hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
     return FMJ_OK;
@@ -1789,6 +1790,12 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->h_b_info2.assign((int*)b_info2.data(), (int*)b_info2.data() + 64 * 4);
   c->h_d_info.assign((int*)d_info.data(), (int*)d_info.data() + 64 * 4);
 
+  {   // subtree mass (a model constant) rides in ipos.w
+    std::vector<double> smass(nb, 0.0);
+    for (int i = 1; i < nb; i++) smass[i] = m->body_mass[i];
+    for (int i = nb - 1; i >= 2; i--) smass[m->body_parentid[i]] += smass[i];
+    for (int i = 1; i < nb; i++) b_ipos[i].w = (float)smass[i];
+  }
   UP(b_anc, b_anc);
   {   // depth of the deepest dof shared by the root chains of two dofs (constraint rows couple only through it)
     std::vector<int8_t> lcad((size_t)r4(nv * nv), (int8_t)-1);
@@ -1988,6 +1995,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
   c->lds_bytes = (size_t)L.total * sizeof(float);
   c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
+  c->lds_bytes_dual2 = D.dual_ok ? (size_t)(2 * lds2_layout(nb, nv, nq, D.rs, D.dual_t0).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
+  { const char* envv = getenv("FMJ_DUAL"); c->dual_gen = (envv && envv[0] == '1') ? 1 : 2; }
   if (c->lds_bytes > 64 * 1024) {
     hipError_t e1 = hipFuncSetAttribute((const void*)pick_kernel(c, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)pick_kernel(c, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -2004,7 +2013,7 @@ int fmj_get_sensor_layout(const fmj_ctx* c, fmj_sensor_layout_t* out) {
 
 int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threads_per_env) {
   if (!c) return set_err(FMJ_ERR_ARG, "fmj_kernel_info: NULL ctx");
-  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)c->lds_bytes;
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)(c->dm.dual_ok ? (c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual) / 2 : c->lds_bytes);
   if (threads_per_env) *threads_per_env = c->dm.dual_ok ? 32 : 64;   // the integrating step packs two envs per wave when it can
   return FMJ_OK;
 }
