@@ -60,6 +60,7 @@ struct DevModel {
   int rs;             // row stride of Hrow (multiple of 4, >= max dof depth + 1)
   int root_free;      // 1 if body 1 carries a free joint
   int any_stiffness, any_box, nsensordata, njs;
+  int any_jpos, any_bquat, any_iquat;   // some hinge anchor off the body origin / some body frame rotated in its parent / some inertial frame rotated in its body
   int n_links, n_joints, n_xfrc, ns;
   int anc_stride;     // bytes per chain row (multiple of 4)
   float h, gx, gy, gz, mtot_inv;
@@ -98,7 +99,7 @@ struct DevModel {
 #define BT_STRIDE 9    // per body: pos_mass, quat, ipos, iquat, inertia, axis_q0, jpos_k, info(int4), info2(int4)
 #define DT_STRIDE 6    // per dof: info(int4), prm, act(int4: first, count, joint-sensor slot, dof parent), lim, sol0, sol1
 #define AT_STRIDE 3    // per actuator (sorted by dof): prm, lim, (source index bits, -, -, -)
-#define ST_STRIDE 3    // per swimming link: c0, c1, c2
+#define ST_STRIDE 4    // per swimming link: c0 (force coefficients, mass), c1 (torque coefficients, height), c2 (density, rows, body), c3 (mass / density, 1 / height)
 #define GT_STRIDE 6    // per geom: info(int4), size, pos, quat, sol0, sol1
 #define PT_STRIDE 2    // per plane: plane, prm
 __device__ __forceinline__ unsigned __float_as_uint_(float f) { return (unsigned)__float_as_int(f); }
@@ -198,6 +199,16 @@ __device__ __forceinline__ q4 axisangle_small(v3 ax, float ang) {
   if (!(fabsf(x) <= 0.25f)) return axisangle(ax, ang);
   const float s = x * fmaf(x2, fmaf(x2, fmaf(x2, -1.0f / 5040.0f, 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
   const float c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 1.0f / 40320.0f, -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
+  q4 r = {c, ax.x * s, ax.y * s, ax.z * s};
+  return r;
+}
+// hinge angles: for half-angles up to pi/2 (|q| <= pi) the Taylor polynomials of degree 11 / 12 are exact to fp32 (sin: x^13/13! <
+// 6e-8, cos: x^14/14! < 7e-9) and cost a third of the range-reduced sincosf, which remains the path for larger angles
+__device__ __forceinline__ q4 axisangle_mid(v3 ax, float ang) {
+  const float x = 0.5f * ang, x2 = x * x;
+  if (!(fabsf(x) <= 1.5707964f)) return axisangle(ax, ang);
+  const float s = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -1.0f / 39916800.0f, 1.0f / 362880.0f), -1.0f / 5040.0f), 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+  const float c = fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, 1.0f / 479001600.0f, -1.0f / 3628800.0f), 1.0f / 40320.0f), -1.0f / 720.0f), 1.0f / 24.0f), -0.5f), 1.0f);
   q4 r = {c, ax.x * s, ax.y * s, ax.z * s};
   return r;
 }
@@ -1749,6 +1760,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     }
   }
   D.any_stiffness = any_k; D.any_box = any_box;
+  D.any_jpos = D.any_bquat = D.any_iquat = 0;
+  for (int i = 1; i < nb; i++) {
+    const int j = m->body_jntadr[i];
+    if (j >= 0 && m->jnt_type[j] != FMJ_JNT_FREE && (m->jnt_pos[3 * j] != 0 || m->jnt_pos[3 * j + 1] != 0 || m->jnt_pos[3 * j + 2] != 0)) D.any_jpos = 1;
+    const bool freeb = j >= 0 && m->jnt_type[j] == FMJ_JNT_FREE;
+    if (!freeb && !(fabs(m->body_quat[4 * i]) == 1.0 && m->body_quat[4 * i + 1] == 0 && m->body_quat[4 * i + 2] == 0 && m->body_quat[4 * i + 3] == 0)) D.any_bquat = 1;
+    if (!(m->body_iquat[4 * i] == 1.0 && m->body_iquat[4 * i + 1] == 0 && m->body_iquat[4 * i + 2] == 0 && m->body_iquat[4 * i + 3] == 0)) D.any_iquat = 1;
+  }
   D.n_links = nb - 1; D.n_joints = njs; D.n_xfrc = nb - 1; D.ns = 0;
   // actuators sorted by dof
   std::vector<float4> a_prm, a_lim; std::vector<int> a_src;
@@ -2038,7 +2057,10 @@ int fmj_set_swimming(fmj_ctx* c, int32_t ns, int32_t n_xfrc_rows, const int32_t*
     c->h_b_info2[4 * b + 3] = s;
   }
   std::vector<float4> stab((ns ? ns : 1) * ST_STRIDE, f4(0, 0, 0, 0));
-  for (int s2 = 0; s2 < ns; s2++) { stab[s2 * ST_STRIDE] = c0[s2]; stab[s2 * ST_STRIDE + 1] = c1[s2]; stab[s2 * ST_STRIDE + 2] = c2[s2]; }
+  for (int s2 = 0; s2 < ns; s2++) {
+    stab[s2 * ST_STRIDE] = c0[s2]; stab[s2 * ST_STRIDE + 1] = c1[s2]; stab[s2 * ST_STRIDE + 2] = c2[s2];
+    stab[s2 * ST_STRIDE + 3] = f4(densities[s2] != 0 ? masses[s2] / densities[s2] : 0.0, heights[s2] != 0 ? 1.0 / heights[s2] : 0.0, 0, 0);
+  }
   int rc;
   if ((rc = upload(c, stab, &c->dm.stab))) return rc;
   if ((rc = sync_tables(c))) return rc;
