@@ -57,7 +57,8 @@ class CFusedArgs(ctypes.Structure):
                 ('ctrl_step_stride', ctypes.c_int64), ('row_stride_links', ctypes.c_int64),
                 ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
                 ('row_stride_contacts', ctypes.c_int64),
-                ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP)]
+                ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP),
+                ('env_order', _VP)]
 
 
 # every symbol include/fmj.h declares: name -> (restype, argtypes)

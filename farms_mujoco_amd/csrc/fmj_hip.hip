@@ -129,6 +129,7 @@ struct StepArgs {
   // wave controller
   const float* w_amp; const float* w_lag; const float* w_env; float w_freq;
   float* ctrl_out;            // fused + wave controller: ctrl of the launch's last step (physics.data.ctrl)
+  const int* env_order;       // one-env kernel: env of workgroup b (NULL: b); heavier envs first shortens a launch's tail
   float* dbg_H; float* dbg_qfrc;   // fmj_forward_debug: rows of H = M + diag(armature + h damping) [n_envs][nv][rs], qfrc_smooth [n_envs][nv]
 };
 
@@ -138,6 +139,7 @@ struct fmj_ctx {
   std::vector<void*> allocs;
   size_t lds_bytes, lds_bytes_dual, lds_bytes_dual2;
   int dual_gen;               // 2: fmj_dual2.inc (default), 1: fmj_dual.inc (FMJ_DUAL=1)
+  int dual_wps;               // waves per SIMD the dual2 build is registered for: 4, or 3 when the batch cannot fill more (FMJ_WPS overrides)
   fmj_sensor_layout_t layout;
   // host copies needed later
   std::vector<int> body_link_row, dof_joint_row, body_swim;
@@ -728,7 +730,7 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 template <bool FUSED, int MAXD, bool CONS>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
-  const int env = blockIdx.x;
+  const int env = A.env_order ? A.env_order[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
@@ -1434,7 +1436,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #define FMJ_CAT2(a, b) a##b
 #define FMJ_CAT(a, b) FMJ_CAT2(a, b)
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
-  if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD>;
+  if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
+  if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
   if (dual) return fused ? (void*)fmj_step_dual_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual_kernel<false, FMJ_TU_MAXD>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
@@ -1588,7 +1591,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, bool cons, int dual) {
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons != 0, 0); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc / fmj_dual.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, false, c->dual_gen);
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, false, c->dual_gen == 2 && c->dual_wps == 3 ? 3 : c->dual_gen);
     hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
@@ -2016,6 +2019,15 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
   c->lds_bytes_dual2 = D.dual_ok ? (size_t)(2 * lds2_layout(nb, nv, nq, D.rs, D.dual_t0).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
   { const char* envv = getenv("FMJ_DUAL"); c->dual_gen = (envv && envv[0] == '1') ? 1 : 2; }
+  {
+    hipDeviceProp_t prop;
+    int n_cu = 256;
+    if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
+    const int waves = (n_envs + 1) / 2;
+    c->dual_wps = waves <= 3 * 4 * n_cu ? 3 : 4;          // at most three waves per SIMD anyway: take the 168-register build (nothing spilled)
+    const char* w = getenv("FMJ_WPS");
+    if (w && (w[0] == '3' || w[0] == '4')) c->dual_wps = w[0] - '0';
+  }
   if (c->lds_bytes > 64 * 1024) {
     hipError_t e1 = hipFuncSetAttribute((const void*)pick_kernel(c, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
     hipError_t e2 = hipFuncSetAttribute((const void*)pick_kernel(c, false), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
@@ -2179,6 +2191,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
   A.ctrl_out = a->controller == 1 ? a->ctrl_out : nullptr;
+  A.env_order = c->dm.dual_ok ? nullptr : a->env_order;
   HIP_TRY(hipSetDevice(c->device));
   return launch_step(c, true, A, stream);
 }

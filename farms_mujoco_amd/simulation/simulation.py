@@ -46,6 +46,7 @@ class Simulation:
         # dm_control raises PhysicsError inside the offending step; here the device freezes the offending env at that
         # step (include/fmj.h) and the host looks at the status words every `check_every` steps (one sync each)
         self.check_every = int(kwargs.pop('check_every', 100))
+        self.order_by_contacts = bool(kwargs.pop('order_by_contacts', True))
         extract_sub_dict(kwargs, ('control_timestep', 'n_sub_steps', 'flat_observation'))
         self.task = ExperimentTask(base_link=base_link, n_iterations=self.options.n_iterations,
                                    timestep=self.options.timestep, units=self.options.units,
@@ -135,6 +136,10 @@ class Simulation:
                                                                      c.env_phase.data_ptr())
             a.wave.frequency = c.frequency
             a.ctrl_out = phys.data.ctrl.data_ptr()       # callbacks reading physics.data.ctrl see the last step's command
+        if phys.has_constraints and self.order_by_contacts:
+            # envs with the most contacts (the slowest to step) are launched first instead of wherever they sit
+            self._env_order = torch.argsort(phys.data.ncon, descending=True, stable=True).to(torch.int32)
+            a.env_order = self._env_order.data_ptr()
         _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
                                             ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
         task.iteration += n_steps

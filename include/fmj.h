@@ -329,6 +329,9 @@ typedef struct fmj_fused_args {
   fmj_wave_controller wave;
   float* ctrl_out;          /* [n_envs,nu] DEVICE or NULL: with controller 1, receives the ctrl of the LAST step of the
                                launch (what physics.data.ctrl holds after task.py:288-346 ran for that iteration) */
+  const int32_t* env_order; /* [n_envs] DEVICE or NULL: a permutation of the envs; workgroup b of the one-env kernel steps
+                               env_order[b].  Results do not depend on it; listing the envs with the most contacts first
+                               keeps them from starting last and setting the launch time (constraint models) */
 } fmj_fused_args;
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);
