@@ -72,6 +72,8 @@ struct DevModel {
   const float4* gtab;         // [ngeom][GT_STRIDE]
   const float4* ptab;         // [nplane][PT_STRIDE]
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
+  const float* hf_data;       // [hf_nrow][hf_ncol] heightfield samples (one heightfield per model)
+  int hf_nrow, hf_ncol;
   float* cons_rows;           // [n_envs][maxefc][8] row parameters of envs with more rows than LDS holds
   float* cons_a;              // [n_envs][maxefc][AG_LD] their PGS matrix
   float* cons_z;              // [n_envs][maxefc][rs] their compact constraint rows
@@ -101,7 +103,7 @@ struct DevModel {
 #define AT_STRIDE 3    // per actuator (sorted by dof): prm, lim, (source index bits, -, -, -)
 #define ST_STRIDE 4    // per swimming link: c0 (force coefficients, mass), c1 (torque coefficients, height), c2 (density, rows, body), c3 (mass / density, 1 / height)
 #define GT_STRIDE 6    // per geom: info(int4), size, pos, quat, sol0, sol1
-#define PT_STRIDE 2    // per plane: plane, prm
+#define PT_STRIDE 4    // per ground geom: plane (n, offset) or heightfield position; prm (friction, heightfield flag, geom id); heightfield quat; heightfield rx, ry, size z
 __device__ __forceinline__ unsigned __float_as_uint_(float f) { return (unsigned)__float_as_int(f); }
 __device__ __forceinline__ int4 as_int4(float4 v) { return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)); }
 #define BTAB(b, k) (M.btab[(unsigned)(b) * BT_STRIDE + (k)])
@@ -634,6 +636,34 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
   } else { K = -sr0 / fmaxf(1e-15f, dmax * dmax); B = -sr1 / fmaxf(1e-15f, dmax); }
   *R = fmaxf(1e-15f, (1.f - imp) * diag_approx / imp);
   *kimp = K * imp; *bb = B;
+}
+
+// Height of world point p above ground entry pl along the local surface normal, and that normal.  Plane: n . p - offset.
+// Heightfield (MuJoCo hfield semantics: nrow x ncol samples over [-rx, rx] x [-ry, ry] of the geom frame, elevation = data *
+// size z): the plane of the grid triangle under p (cells split along the diagonal (c, r) - (c + 1, r + 1)); nothing outside
+// the grid.  PTAB(pl, 1).y != 0 marks a heightfield, PTAB(pl, 0) then holds its position, (pl, 2) its quaternion, (pl, 3)
+// rx, ry, size z.
+__device__ __forceinline__ float ground_dist(const DevModel& M, int pl, float4 pn, float4 pp, v3 p, v3* n) {
+  if (pp.y == 0.f) { *n = mk3(pn.x, pn.y, pn.z); return dot3(p, *n) - pn.w; }
+  const float4 hq = PTAB(pl, 2), hs = PTAB(pl, 3);
+  const q4 q = {hq.x, hq.y, hq.z, hq.w}, qc = {hq.x, -hq.y, -hq.z, -hq.w};
+  const v3 pl_ = qrot(qc, sub3(p, mk3(pn.x, pn.y, pn.z)));
+  const int nc = M.hf_ncol, nr = M.hf_nrow;
+  const float sx = (float)(nc - 1) / (2.f * hs.x), sy = (float)(nr - 1) / (2.f * hs.y);
+  const float gx = (pl_.x + hs.x) * sx, gy = (pl_.y + hs.y) * sy;
+  *n = qrot(q, mk3(0.f, 0.f, 1.f));
+  if (!(gx >= 0.f && gx <= (float)(nc - 1) && gy >= 0.f && gy <= (float)(nr - 1))) return 1e30f;
+  const int c = min((int)gx, nc - 2), r = min((int)gy, nr - 2);
+  const float fx = gx - (float)c, fy = gy - (float)r;
+  const float* D = M.hf_data + (size_t)r * nc + c;
+  const float z00 = D[0] * hs.z, z10 = D[1] * hs.z, z01 = D[nc] * hs.z, z11 = D[nc + 1] * hs.z;
+  float zs, gxs, gys;                                          // surface height under p and its slopes per cell
+  if (fx >= fy) { gxs = z10 - z00; gys = z11 - z10; } else { gxs = z11 - z01; gys = z01 - z00; }
+  zs = z00 + gxs * fx + gys * fy;
+  const v3 nl = mk3(-gxs * sx, -gys * sy, 1.f);
+  const float inv = 1.0f / sqrtf(dot3(nl, nl));
+  *n = qrot(q, scl3(nl, inv));
+  return (pl_.z - zs) * inv;                                   // n_z (p_z - z_surface)
 }
 
 // One contact-sensor row (reference sensors.pyx:20-137,158-182): accumulate every contact whose keys hit `row`.
@@ -1222,17 +1252,19 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       const int e_lo = __popcll(m_lo & lt) + __popcll(m_hi & lt);
       const int e_hi = e_lo + (act_lo ? 1 : 0);
       const int nlim = __popcll(m_lo) + __popcll(m_hi);
-      // (3) plane contacts: lane = geom; contacts ordered by (plane, geom, segment) like the oracle
+      // (3) ground contacts: lane = geom; contacts ordered by (ground geom, geom, point) like the oracle.  A ground entry is a
+      //     world-attached plane or heightfield; the heightfield is met as the plane of the grid triangle under each
+      //     candidate point (ground_dist), so every contact carries its own normal.
       int ncon = 0;
       for (int pl = 0; pl < M.nplane; pl++) {
         const float4 pn = PTAB(pl, 0), pp = PTAB(pl, 1);
         for (int g0 = 0; g0 < M.ngeom; g0 += 64) {
           const int g = g0 + lane;
           // up to 4 contacts per geom: sphere 1, capsule 2 (segment ends), box the first 4 penetrating corners in
-          // corner order (what the oracle's collide_plane does)
-          int cnt = 0; v3 cq[4]; float dq[4]; float rad = 0.f, mu = 0.f;
+          // corner order (what the oracle's collide_ground does), cylinder its rim points
+          int cnt = 0; v3 cq[4], nq[4]; float dq[4]; float rad = 0.f, mu = 0.f;
 #pragma unroll
-          for (int k = 0; k < 4; k++) { cq[k] = mk3(0.f, 0.f, 0.f); dq[k] = 0.f; }
+          for (int k = 0; k < 4; k++) { cq[k] = mk3(0.f, 0.f, 0.f); nq[k] = mk3(0.f, 0.f, 1.f); dq[k] = 0.f; }
           if (g < M.ngeom) {
             const int4 gi = GTABI(g, 0);
             if (gi.x == FMJ_GEOM_SPHERE || gi.x == FMJ_GEOM_CAPSULE) {
@@ -1244,11 +1276,12 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               v3 ax = mk3(0.f, 0.f, 0.f);
               if (gi.x == FMJ_GEOM_CAPSULE) { const q4 gqq = {gq.x, gq.y, gq.z, gq.w}; ax = scl3(qrot(qmul(bqq, gqq), mk3(0.f, 0.f, 1.f)), gs.y); }
               const v3 c0 = add3(cen, ax), c1 = sub3(cen, ax);
-              const float d0 = dot3(c0, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
-              const float d1 = dot3(c1, mk3(pn.x, pn.y, pn.z)) - pn.w - rad;
+              v3 n0, n1;
+              const float d0 = ground_dist(M, pl, pn, pp, c0, &n0) - rad;
+              const float d1 = ground_dist(M, pl, pn, pp, c1, &n1) - rad;
               const bool a0 = d0 < 0.f, a1 = gi.x == FMJ_GEOM_CAPSULE && d1 < 0.f;
-              if (a0) { cq[0] = c0; dq[0] = d0; cnt = 1; }
-              if (a1) { if (cnt == 0) { cq[0] = c1; dq[0] = d1; } else { cq[1] = c1; dq[1] = d1; } cnt++; }
+              if (a0) { cq[0] = c0; dq[0] = d0; nq[0] = n0; cnt = 1; }
+              if (a1) { if (cnt == 0) { cq[0] = c1; dq[0] = d1; nq[0] = n1; } else { cq[1] = c1; dq[1] = d1; nq[1] = n1; } cnt++; }
             }
           }
           if (M.any_box) {
@@ -1264,24 +1297,25 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
               for (int corner = 0; corner < 8; corner++) {
                 const v3 c = add3(add3(cen, (corner & 1) ? ex : scl3(ex, -1.f)), add3((corner & 2) ? ey : scl3(ey, -1.f), (corner & 4) ? ez : scl3(ez, -1.f)));
-                const float d = dot3(c, mk3(pn.x, pn.y, pn.z)) - pn.w;
+                v3 nc;
+                const float d = ground_dist(M, pl, pn, pp, c, &nc);
                 const bool pen = d < 0.f && cnt < 4;
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (pen && cnt == k) { cq[k] = c; dq[k] = d; }
+                for (int k = 0; k < 4; k++) if (pen && cnt == k) { cq[k] = c; dq[k] = d; nq[k] = nc; }
                 cnt += pen ? 1 : 0;
               }
             }
-            if (gi.x == FMJ_GEOM_CYLINDER) {      // rim points (the oracle's collide_plane, MuJoCo's mjc_PlaneCylinder construction)
+            if (gi.x == FMJ_GEOM_CYLINDER) {      // rim points (the oracle's collide_ground, MuJoCo's mjc_PlaneCylinder construction)
               const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
               const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
               const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
               const q4 wq = qmul(bqq, gqq);
               const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
-              const v3 nrm_ = mk3(pn.x, pn.y, pn.z);
+              v3 nrm_;                                         // a heightfield is taken as the plane under the cylinder's centre
+              const float dist = ground_dist(M, pl, pn, pp, cen, &nrm_);
               v3 axis = qrot(wq, mk3(0.f, 0.f, 1.f));
               float prjaxis = dot3(nrm_, axis);
               if (prjaxis > 0.f) { axis = scl3(axis, -1.f); prjaxis = -prjaxis; }
-              const float dist = dot3(cen, nrm_) - pn.w;
               v3 vec = sub3(scl3(axis, prjaxis), nrm_);
               const float len2 = dot3(vec, vec);
               if (len2 >= 1e-30f) vec = scl3(vec, gs.x / sqrtf(len2)); else vec = scl3(qrot(wq, mk3(1.f, 0.f, 0.f)), gs.x);
@@ -1308,6 +1342,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
                   cnt += pen ? 1 : 0;
                 }
               }
+#pragma unroll
+              for (int k = 0; k < 4; k++) nq[k] = nrm_;
             }
           }
           int before = 0, total = 0;
@@ -1315,16 +1351,16 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           for (int k = 0; k < 4; k++) { const unsigned long long bk = __ballot(cnt > k); before += __popcll(bk & lt); total += __popcll(bk); }
           const int s0 = ncon + before;
           ncon += total;
-          // frame: x = normal, t1 from (0,1,0) or (0,0,1) made orthogonal, t2 = n x t1 (mju_makeFrame)
-          v3 nrm = mk3(pn.x, pn.y, pn.z);
-          v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
-          t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
-          t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
-          const v3 t2 = cross(nrm, t1);
 #pragma unroll
           for (int k = 0; k < 4; k++) {
             const int slot = s0 + k;
             if (k < cnt && slot < M.max_contacts) {
+              // frame: x = normal, t1 from (0,1,0) or (0,0,1) made orthogonal, t2 = n x t1 (mju_makeFrame)
+              const v3 nrm = nq[k];
+              v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
+              t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
+              t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
+              const v3 t2 = cross(nrm, t1);
               const v3 pos = sub3(cq[k], scl3(nrm, rad + 0.5f * dq[k]));
               float* ct = CT + slot * 16;
               *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
@@ -1644,12 +1680,19 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
   const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
   if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
-  int any_limit = 0, nplane = 0, any_box = 0;
+  int any_limit = 0, nplane = 0, any_box = 0, n_hfield = 0;     // nplane counts the ground geoms: planes and the heightfield
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE) any_limit = 1;
   for (int g = 0; g < m->ngeom; g++) {
     int t = m->geom_type[g];
     if (t == FMJ_GEOM_PLANE) { if (m->geom_bodyid[g] != 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: planes must be attached to the world body"); nplane++; }
-    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX && t != FMJ_GEOM_CYLINDER) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / sphere / capsule / cylinder / box geoms are in the HIP path");
+    else if (t == FMJ_GEOM_HFIELD) {
+      if (m->geom_bodyid[g] != 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: heightfields must be attached to the world body");
+      if (n_hfield++) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: one heightfield geom per model");
+      if (m->hfield_nrow < 2 || m->hfield_ncol < 2 || !m->hfield_data || !(m->hfield_size[0] > 0) || !(m->hfield_size[1] > 0))
+        return set_err(FMJ_ERR_ARG, "fmj_create: heightfield needs nrow, ncol >= 2, data and positive x / y radii");
+      nplane++;
+    }
+    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX && t != FMJ_GEOM_CYLINDER) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / heightfield / sphere / capsule / cylinder / box geoms are in the HIP path");
     else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
     if (t == FMJ_GEOM_BOX || t == FMJ_GEOM_CYLINDER) any_box = 1;      // geoms with up to 4 contacts
   }
@@ -1846,7 +1889,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   std::vector<int> d_parent(64, -1);
   for (int d = 0; d < nv; d++) d_parent[d] = m->dof_parentid[d];
   std::vector<int4> g_info(m->ngeom ? m->ngeom : 1); std::vector<float4> g_size(g_info.size()), g_pos(g_info.size()), g_quat(g_info.size()), g_sol0(g_info.size()), g_sol1(g_info.size());
-  std::vector<float4> p_plane(nplane ? nplane : 1), p_prm(nplane ? nplane : 1);
+  std::vector<float4> p_plane(nplane ? nplane : 1), p_prm(nplane ? nplane : 1), p_hq(nplane ? nplane : 1, f4(1, 0, 0, 0)), p_hs(nplane ? nplane : 1, f4(1, 1, 0, 0));
   std::vector<float4> d_lim(64, f4(0, 0, 0, 0)), d_sol0(64, f4(0.02, 1, 0.9, 0.95)), d_sol1(64, f4(0.001, 0.5, 2, 0));
   if (cons) {
     int ip = 0;
@@ -1867,6 +1910,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
         double nn = sqrt(nx * nx + ny * ny + nz * nz); nx /= nn; ny /= nn; nz /= nn;
         p_plane[ip] = f4(nx, ny, nz, nx * p[0] + ny * p[1] + nz * p[2]);
         p_prm[ip] = make_float4((float)m->geom_friction[3 * g], 0.f, ibits(g), 0.f);
+        ip++;
+      }
+      if (m->geom_type[g] == FMJ_GEOM_HFIELD) {     // position, flag, frame, extent: see ground_dist
+        const double* q = m->geom_quat + 4 * g; const double* p = m->geom_pos + 3 * g;
+        p_plane[ip] = f4(p[0], p[1], p[2], 0);
+        p_prm[ip] = make_float4((float)m->geom_friction[3 * g], 1.f, ibits(g), 0.f);
+        p_hq[ip] = f4(q[0], q[1], q[2], q[3]);
+        p_hs[ip] = f4(m->hfield_size[0], m->hfield_size[1], m->hfield_size[2], m->hfield_size[3]);
         ip++;
       }
     }
@@ -1896,7 +1947,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   for (int e2 = 0; e2 < nMpad; e2++) mtab[e2] = make_float4(ibits((int)m_tab[e2]), m_add[e2], m_arm[e2], 0.f);
   std::vector<float4> gtab(g_info.size() * GT_STRIDE), ptab(p_plane.size() * PT_STRIDE);
   for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
-  for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; }
+  for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; ptab[p * PT_STRIDE + 2] = p_hq[p]; ptab[p * PT_STRIDE + 3] = p_hs[p]; }
+  D.hf_nrow = D.hf_ncol = 0; D.hf_data = nullptr;
+  if (n_hfield) {
+    std::vector<float> hf((size_t)m->hfield_nrow * m->hfield_ncol);
+    for (size_t i = 0; i < hf.size(); i++) hf[i] = (float)m->hfield_data[i];
+    D.hf_nrow = m->hfield_nrow; D.hf_ncol = m->hfield_ncol;
+    UP(hf, hf_data);
+  }
   c->h_atab = atab; c->a_src = a_src;
   UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(mtab, mtab); UP(gtab, gtab); UP(ptab, ptab);
   {   // two envs per wave: bodies and the dofs minus a free root's translational dofs must fit 32 lanes
@@ -1998,7 +2056,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   { std::vector<float4> empty4(ST_STRIDE, f4(0, 0, 0, 0)); UP(empty4, stab); }
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
   c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
-  for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE;
+  for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE || m->geom_type[g] == FMJ_GEOM_HFIELD;
   D.cons_rows = nullptr; D.cons_a = nullptr; D.cons_z = nullptr;
   if (D.cons && D.maxefc > 0) {   // HBM scratch of envs whose constraint rows outgrow LDS (fmj_step_kernel<.., CONS = true>, "big" path)
     void* p1 = nullptr; void* p2 = nullptr;

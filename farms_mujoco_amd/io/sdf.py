@@ -1,6 +1,6 @@
 """Minimal SDF reader — stand-in for farms_core.io.sdf (ModelSDF, Link, Joint, Collision, shapes), which the
 reference imports (reference mjcf.py:30-33) but does not vendor.  Only what the model compiler consumes is parsed:
-link poses, inertials, collision geometry (sphere / capsule / cylinder / box / plane) and joints."""
+link poses, inertials, collision geometry (sphere / capsule / cylinder / box / plane / heightmap) and joints."""
 from __future__ import annotations
 
 import os
@@ -21,8 +21,9 @@ def _floats(text, n=None, default=None):
 
 @dataclass
 class Geometry:
-    kind: str                       # 'sphere' | 'capsule' | 'cylinder' | 'box' | 'plane' | 'mesh'
-    size: np.ndarray                # sphere: [r]; capsule/cylinder: [r, length]; box: [x, y, z]; plane: normal
+    kind: str                       # 'sphere' | 'capsule' | 'cylinder' | 'box' | 'plane' | 'heightmap' | 'mesh'
+    size: np.ndarray                # sphere: [r]; capsule/cylinder: [r, length]; box: [x, y, z]; plane: normal; heightmap: [x, y, z] extents
+    uri: str = ''                   # heightmap: image file, relative to the SDF's directory
 
     def bounding_radius(self) -> float:
         """MuJoCo geom_rbound of the shape (used for SwimmingHandler heights, reference drag.pyx:364-372)."""
@@ -109,7 +110,7 @@ class ModelSDF:
             for ce in le.findall('collision'):
                 ge = ce.find('geometry')
                 geo = None
-                for kind in ('sphere', 'capsule', 'cylinder', 'box', 'plane', 'mesh'):
+                for kind in ('sphere', 'capsule', 'cylinder', 'box', 'plane', 'heightmap', 'mesh'):
                     k = ge.find(kind)
                     if k is None:
                         continue
@@ -122,6 +123,8 @@ class ModelSDF:
                     elif kind == 'plane':
                         n = k.find('normal')
                         geo = Geometry(kind, _floats(n.text if n is not None else '0 0 1', 3))
+                    elif kind == 'heightmap':
+                        geo = Geometry(kind, _floats(k.find('size').text, 3), uri=k.find('uri').text.strip())
                     else:
                         geo = Geometry(kind, np.zeros(3))
                 cols.append(Collision(ce.get('name', f'{le.get("name")}_collision'), pose_of(ce), geo))

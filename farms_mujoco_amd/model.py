@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 2, 3, 5, 6
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 1, 2, 3, 5, 6
 ABI_VERSION = 2
 
 DEFAULT_SOLREF = (0.02, 1.0)
@@ -115,6 +115,7 @@ class ModelBuilder:
         self.bodies: List[_Body] = [_Body('world', -1, np.zeros(3), np.array([1., 0, 0, 0]), 0.0,
                                           np.zeros(3), np.array([1., 0, 0, 0]), np.zeros(3))]
         self.actuators: List[dict] = []
+        self.hfield: Optional[dict] = None
         self.options = dict(solver_iterations=50, max_contacts=0, impratio=1.0, solver_tolerance=1e-8)
 
     def body_id(self, name: str) -> int:
@@ -179,6 +180,16 @@ class ModelBuilder:
                             friction=np.asarray(friction, float), solref=np.asarray(solref, float),
                             solimp=np.asarray(solimp, float)))
 
+    def add_hfield(self, data, size, pos=(0, 0, 0), quat=(1, 0, 0, 0), friction=(0, 0, 0), solref=DEFAULT_SOLREF,
+                   solimp=DEFAULT_SOLIMP):
+        """World-attached heightfield (reference mjcf.py:486-522): ``data`` [nrow, ncol] with rows along +y and columns
+        along +x, ``size`` = (x radius, y radius, elevation scale, base depth) as MuJoCo's hfield asset; elevation =
+        data * size[2]."""
+        data = np.ascontiguousarray(data, float)
+        assert data.ndim == 2 and min(data.shape) >= 2 and self.hfield is None, 'one heightfield with at least 2 x 2 samples'
+        self.hfield = dict(data=data, size=np.asarray(size, float).reshape(4))
+        self.add_geom('world', GEOM_HFIELD, (0, 0, 0), pos=pos, quat=quat, friction=friction, solref=solref, solimp=solimp)
+
     def add_joint_actuators(self, joint_name, kp=0.0, kv=0.0, forcerange=None, pos_limits=None, vel_limits=None):
         """The position / velocity / motor triple of reference mjcf.py:819-866.  ``forcerange`` = the motor's
         ``limits_torque`` applied to all three (:855-865); ``pos_limits`` / ``vel_limits`` = dict(ctrllimited, ctrlrange,
@@ -225,6 +236,7 @@ _CMODEL_FIELDS = (
         [('geom_type', _I), ('geom_bodyid', _I)] +
         [(n, _D) for n in ('geom_size', 'geom_pos', 'geom_quat', 'geom_friction', 'geom_solref', 'geom_solimp',
                            'body_invweight0')] +
+        [('hfield_nrow', ctypes.c_int32), ('hfield_ncol', ctypes.c_int32), ('hfield_size', ctypes.c_double*4), ('hfield_data', _D)] +
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
          ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)]
 )
@@ -397,6 +409,9 @@ class Model:
         m.geom_friction = np.array([g['friction'] for _, g in geoms], float).reshape(-1, 3)
         m.geom_solref = np.array([g['solref'] for _, g in geoms], float).reshape(-1, 2)
         m.geom_solimp = np.array([g['solimp'] for _, g in geoms], float).reshape(-1, 5)
+        m.hfield_nrow, m.hfield_ncol = (b.hfield['data'].shape if b.hfield is not None else (0, 0))
+        m.hfield_size = b.hfield['size'].copy() if b.hfield is not None else np.zeros(4)
+        m.hfield_data = b.hfield['data'].copy() if b.hfield is not None else None
         m.solver_iterations = int(b.options['solver_iterations'])
         m.max_contacts = int(b.options['max_contacts'])
         m.impratio = float(b.options['impratio'])
@@ -474,6 +489,12 @@ class Model:
         c.impratio = self.impratio
         c.solver_tolerance = self.solver_tolerance
         c.meaninertia = self.meaninertia
+        c.hfield_nrow, c.hfield_ncol = int(getattr(self, 'hfield_nrow', 0)), int(getattr(self, 'hfield_ncol', 0))
+        c.hfield_size = (ctypes.c_double*4)(*np.asarray(getattr(self, 'hfield_size', np.zeros(4)), float))
+        hd = getattr(self, 'hfield_data', None)
+        if hd is not None:
+            keep['hfield_data'] = np.ascontiguousarray(hd, np.float64).ravel()
+            c.hfield_data = keep['hfield_data'].ctypes.data_as(ctypes.POINTER(ctypes.c_double))
         for n in _INT_FIELDS:
             a = np.ascontiguousarray(getattr(self, n), np.int32)
             if a.size == 0:

@@ -49,9 +49,14 @@ class WaterOptions:
 
 
 class ArenaOptions:
+    """farms_core ArenaOptions surface (reference mjcf.py:1195-1225): ``sdf`` (arena model: a plane or a heightmap),
+    ``spawn.pose``, ``ground_height``, ``water``."""
+
     def __init__(self, **kwargs):
         self.water = kwargs.pop('water', WaterOptions())
         self.ground_height = kwargs.pop('ground_height', None)
+        self.sdf = kwargs.pop('sdf', None)
+        self.spawn = SimpleNamespace(pose=list(kwargs.pop('spawn_pose', [0, 0, 0, 0, 0, 0])))
         assert not kwargs, kwargs
 
 

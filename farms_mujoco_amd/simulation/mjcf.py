@@ -10,7 +10,7 @@ from __future__ import annotations
 import numpy as np
 
 from ..io.sdf import ModelSDF, Link
-from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, DEFAULT_SOLREF,
+from ..model import (ModelBuilder, Model, euler2quat, quat2mat, GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, DEFAULT_SOLREF,
                      DEFAULT_SOLIMP)
 from ..units import SimulationUnitScaling
 
@@ -65,6 +65,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     use_actuators = kwargs.pop('use_actuators', True)
     use_collisions = kwargs.pop('use_collisions', False)
     plane = kwargs.pop('plane', False)
+    hfield = kwargs.pop('hfield', None)
     friction = kwargs.pop('friction', [0, 0, 0])
     solref = kwargs.pop('solref', None)
     solimp = kwargs.pop('solimp', None)
@@ -181,6 +182,10 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     if plane:
         b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))            # arena friction 0 (mjcf.py:1202)
         b.options['max_contacts'] = int(plane) if not isinstance(plane, bool) else 32
+    if hfield is not None:                                                        # arena heightmap (mjcf.py:486-522)
+        b.add_hfield(hfield['data'], hfield['size'], pos=hfield.get('pos', (0, 0, 0)), quat=hfield.get('quat', (1, 0, 0, 0)),
+                     friction=(0, 0, 0))
+        b.options['max_contacts'] = max(int(b.options['max_contacts']), 32)
 
     # actuators: position / velocity / motor per joint (:791-866)
     if use_actuators:
@@ -210,14 +215,49 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     return m
 
 
+def arena_heightfield(arena_options, units=None):
+    """The heightmap collision of the arena SDF as a heightfield description (reference mjcf.py:486-522 for the asset,
+    :1195-1212 for the arena pose, task.py:108-115 for the data: hfield_data = 2 (image - 0.5), image normalised to
+    [0, 1] and flipped to Cartesian rows).  None when the arena SDF holds no heightmap."""
+    import os
+    from ..io.png import imread
+    units = units or SimulationUnitScaling()
+    path = getattr(arena_options, 'sdf', None)
+    if not path:
+        return None
+    arena = ModelSDF.read(os.path.expandvars(path))[0]
+    for link in arena.links:
+        for col in link.collisions:
+            g = col.geometry
+            if g is None or g.kind != 'heightmap':
+                continue
+            img = imread(os.path.join(arena.directory, g.uri))
+            img = img[:, :, 0] if img.ndim == 3 else img[:, :]                      # RGB vs grey (:492)
+            vmin, vmax = np.iinfo(img.dtype).min, np.iinfo(img.dtype).max
+            data = np.flip((img.astype(float) - vmin)/(vmax - vmin), axis=0)       # normalise, Cartesian rows (:493-495)
+            spawn = getattr(getattr(arena_options, 'spawn', None), 'pose', [0]*6)
+            pos = np.array(spawn[:3], float) + np.array(link.pose[:3]) + np.array(col.pose[:3])
+            if getattr(arena_options, 'ground_height', None) is not None:
+                pos[2] += arena_options.ground_height                             # :1210-1211
+            return dict(data=2*(data - 0.5),                                        # task.py:115
+                        size=(0.5*g.size[0]*units.meters, 0.5*g.size[1]*units.meters, 0.5*g.size[2]*units.meters,
+                              g.size[2]*units.meters),                              # :505-510
+                        pos=pos*units.meters, quat=euler2mjcquat(np.array(spawn[3:], float) + np.array(link.pose[3:])),
+                        image=data)
+    return None
+
+
 def setup_model(simulation_options, animat_options, arena_options=None, **kwargs) -> Model:
     """setup_mjcf_xml counterpart (reference mjcf.py:1174-1512): read the animat SDF named by the options and
-    compile it; a flat arena with ``ground_height`` becomes the collision plane."""
+    compile it; a flat arena with ``ground_height`` becomes the collision plane, an arena SDF with a heightmap the
+    heightfield."""
     sdf = ModelSDF.read(animat_options.sdf)[0]
-    plane = arena_options is not None and getattr(arena_options, 'ground_height', None) is not None
+    units = simulation_options.units if simulation_options is not None else SimulationUnitScaling()
+    hfield = arena_heightfield(arena_options, units) if arena_options is not None else None
+    plane = hfield is None and arena_options is not None and getattr(arena_options, 'ground_height', None) is not None
     mujoco_kw = dict(getattr(animat_options, 'mujoco', {}) or {})
-    return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options,
-                     fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane, plane=plane,
+    return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options, hfield=hfield,
+                     fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane or hfield is not None, plane=plane,
                      **{k: v for k, v in mujoco_kw.items()
                         if k in ('solref', 'solimp', 'friction') or k.startswith(('act_pos_', 'act_vel_'))}, **kwargs)
 
@@ -241,7 +281,7 @@ def model2mjcf_xml(m: Model) -> str:
     ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))
     world = ET.SubElement(root, 'worldbody')
     elems = {0: world}
-    gtypes = {GEOM_PLANE: 'plane', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_CYLINDER: 'cylinder', GEOM_BOX: 'box'}
+    gtypes = {GEOM_PLANE: 'plane', 1: 'hfield', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_CYLINDER: 'cylinder', GEOM_BOX: 'box'}
     for b in range(1, m.nbody):
         e = ET.SubElement(elems[int(m.body_parentid[b])], 'body', name=m.body_names[b], pos=v(m.body_pos[b]), quat=v(m.body_quat[b]))
         elems[b] = e
@@ -263,7 +303,7 @@ def model2mjcf_xml(m: Model) -> str:
                 ET.SubElement(e, 'joint', **at)
     for g in range(m.ngeom):
         t = int(m.geom_type[g])
-        size = {GEOM_PLANE: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
+        size = {GEOM_PLANE: [1, 1, 0.1], 1: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
         ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]),
                       friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]), solimp=v(m.geom_solimp[g]), condim='3', margin='0')
     if m.nu:

@@ -38,7 +38,7 @@ enum {
 
 /* ---- joint / geom enums (values follow MuJoCo's mjtJoint / mjtGeom) ---------------------- */
 enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, FMJ_JNT_HINGE = 3 };
-enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6 };   /* mjtGeom values */
+enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
  * reference simulation.py:157-161,176-179).  An env whose status carries one of the BAD* bits is FROZEN: from the
@@ -131,9 +131,11 @@ typedef struct fmj_model {
   const int32_t* actuator_forcelimited;
   const double* actuator_forcerange; /* [nu,2] (task.py:279-286 rewrites this at run time) */
 
-  /* collision geoms [ngeom] (config 4: animat geoms vs plane; reference mjcf.py:251-527).  Supported pairs: plane
-   * (world-attached) against sphere (1 contact), capsule (2: segment ends), cylinder (rim points: up to 4) and box
-   * (first 4 penetrating corners). */
+  /* collision geoms [ngeom] (config 4: animat geoms vs arena; reference mjcf.py:251-527).  Supported pairs: a ground geom
+   * (world-attached plane, or ONE world-attached heightfield, reference mjcf.py:486-522 / task.py:108-123) against sphere
+   * (1 contact), capsule (2: segment ends), cylinder (rim points: up to 4) and box (first 4 penetrating corners).  The
+   * heightfield is met as the plane of the grid triangle under each candidate point ("plane per cell").  At most 192
+   * constraint rows per env: limited joints + 4 * max_contacts <= 192. */
   const int32_t* geom_type;     /* FMJ_GEOM_* */
   const int32_t* geom_bodyid;
   const double* geom_size;      /* [ngeom,3] MuJoCo sizes: sphere r; capsule / cylinder r, half length; box half extents */
@@ -143,6 +145,12 @@ typedef struct fmj_model {
   const double* geom_solref;    /* [ngeom,2] */
   const double* geom_solimp;    /* [ngeom,5] */
   const double* body_invweight0;/* [nbody,2] translational, rotational */
+  /* the heightfield asset of the FMJ_GEOM_HFIELD geom (mjModel.hfield_*): nrow x ncol samples, row-major with the row
+   * along +y and the column along +x of the geom frame, over [-size[0], size[0]] x [-size[1], size[1]]; elevation =
+   * data * size[2] (the reference stores 2 * (image - 0.5) in hfield_data, task.py:108-115); size[3] = base depth, unused */
+  int32_t hfield_nrow, hfield_ncol;
+  double hfield_size[4];
+  const double* hfield_data;    /* [nrow*ncol] or NULL */
 
   /* constraint solver options (mjcf.py:1330-1403) */
   int32_t solver_iterations;

@@ -496,15 +496,45 @@ static void add_contact(const fmj_model* m, ws_t* w, int p, int g, const double*
   cross3(f + 6, f, f + 3);
 }
 
-static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) {
-  /* plane pose */
+/* Height of world point pt above ground geom p (plane or heightfield) along the local surface normal n.
+ * Heightfield (MuJoCo hfield semantics, see include/fmj.h): the plane of the grid triangle under the point, cells split
+ * along the diagonal (c, r) - (c + 1, r + 1); nothing outside the grid. */
+static double ground_dist(const fmj_model* m, const ws_t* w, int p, const double* pt, double* n) {
   int pb = m->geom_bodyid[p];
   double pq[4], ppos[3], v[3], pm[9];
   mul_quat(pq, w->xquat + 4 * pb, m->geom_quat + 4 * p);
   rot_vec_quat(v, m->geom_pos + 3 * p, w->xquat + 4 * pb);
   for (int k = 0; k < 3; k++) ppos[k] = w->xpos[3 * pb + k] + v[k];
   quat2mat(pm, pq);
-  double n[3] = {pm[2], pm[5], pm[8]};
+  double dif[3]; for (int k = 0; k < 3; k++) dif[k] = pt[k] - ppos[k];
+  if (m->geom_type[p] == FMJ_GEOM_PLANE) {
+    n[0] = pm[2]; n[1] = pm[5]; n[2] = pm[8];
+    return dotn(dif, n, 3);
+  }
+  /* heightfield: local coordinates of the point */
+  double lx = pm[0] * dif[0] + pm[3] * dif[1] + pm[6] * dif[2], ly = pm[1] * dif[0] + pm[4] * dif[1] + pm[7] * dif[2],
+         lz = pm[2] * dif[0] + pm[5] * dif[1] + pm[8] * dif[2];
+  int nc = m->hfield_ncol, nr = m->hfield_nrow;
+  double rx = m->hfield_size[0], ry = m->hfield_size[1], zt = m->hfield_size[2];
+  double sx = (nc - 1) / (2 * rx), sy = (nr - 1) / (2 * ry);
+  double gx = (lx + rx) * sx, gy = (ly + ry) * sy;
+  n[0] = pm[2]; n[1] = pm[5]; n[2] = pm[8];
+  if (!(gx >= 0 && gx <= nc - 1 && gy >= 0 && gy <= nr - 1)) return 1e30;
+  int c = (int)gx, r = (int)gy; if (c > nc - 2) c = nc - 2; if (r > nr - 2) r = nr - 2;
+  double fx = gx - c, fy = gy - r;
+  const double* D = m->hfield_data + (size_t)r * nc + c;
+  double z00 = D[0] * zt, z10 = D[1] * zt, z01 = D[nc] * zt, z11 = D[nc + 1] * zt, gxs, gys;
+  if (fx >= fy) { gxs = z10 - z00; gys = z11 - z10; } else { gxs = z11 - z01; gys = z01 - z00; }
+  double zs = z00 + gxs * fx + gys * fy;
+  double nl[3] = {-gxs * sx, -gys * sy, 1.0}, inv = 1.0 / sqrt(dotn(nl, nl, 3));
+  for (int k = 0; k < 3; k++) nl[k] *= inv;
+  for (int k = 0; k < 3; k++) n[k] = pm[3 * k] * nl[0] + pm[3 * k + 1] * nl[1] + pm[3 * k + 2] * nl[2];
+  return (lz - zs) * inv;
+}
+
+/* ground narrow phase: geom 'g' (sphere / capsule / cylinder / box) vs the ground geom 'p' (plane or heightfield) */
+static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) {
+  double v[3], n[3];
   /* geom pose */
   int gb = m->geom_bodyid[g];
   double gq[4], gpos[3], gm[9];
@@ -521,8 +551,7 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
       double c[3];
       double sgn = nseg == 2 ? (s == 0 ? 1.0 : -1.0) : 0.0;
       for (int k = 0; k < 3; k++) c[k] = gpos[k] + sgn * size[1] * gm[3 * k + 2];
-      double dif[3]; for (int k = 0; k < 3; k++) dif[k] = c[k] - ppos[k];
-      double dist = dotn(dif, n, 3) - size[0];
+      double dist = ground_dist(m, w, p, c, n) - size[0];
       if (dist < 0) {  /* margin = 0 (mjcf.py:253) */
         double pos[3];
         for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * (size[0] + 0.5 * dist);
@@ -532,12 +561,12 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
   } else if (type == FMJ_GEOM_CYLINDER) {
     /* plane - cylinder, MuJoCo's published rim-point construction (mjc_PlaneCylinder; restated, not compiled from
      * MuJoCo): the rim point deepest into the plane on the near disk, the same point on the far disk, then two points
-     * at +-120 degrees on the near rim.  margin = 0 (reference mjcf.py:253). */
-    double axis[3] = {gm[2], gm[5], gm[8]}, vec[3], vec1[3], dif[3];
+     * at +-120 degrees on the near rim.  margin = 0 (reference mjcf.py:253).  A heightfield is taken as the plane under
+     * the cylinder's centre. */
+    double axis[3] = {gm[2], gm[5], gm[8]}, vec[3], vec1[3];
+    double dist = ground_dist(m, w, p, gpos, n);
     double prjaxis = dotn(n, axis, 3);
     if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
-    for (int k = 0; k < 3; k++) dif[k] = gpos[k] - ppos[k];
-    double dist = dotn(n, dif, 3);
     for (int k = 0; k < 3; k++) vec[k] = axis[k] * prjaxis - n[k];
     double len2 = dotn(vec, vec, 3);
     if (len2 >= 1e-30) { double sc = size[0] / sqrt(len2); for (int k = 0; k < 3; k++) vec[k] *= sc; }
@@ -573,8 +602,7 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
       double loc[3] = {(corner & 1 ? 1 : -1) * size[0], (corner & 2 ? 1 : -1) * size[1], (corner & 4 ? 1 : -1) * size[2]};
       double c[3];
       for (int k = 0; k < 3; k++) c[k] = gpos[k] + gm[3 * k] * loc[0] + gm[3 * k + 1] * loc[1] + gm[3 * k + 2] * loc[2];
-      double dif[3]; for (int k = 0; k < 3; k++) dif[k] = c[k] - ppos[k];
-      double dist = dotn(dif, n, 3);
+      double dist = ground_dist(m, w, p, c, n);
       if (dist < 0) {
         double pos[3];
         for (int k = 0; k < 3; k++) pos[k] = c[k] - n[k] * 0.5 * dist;
@@ -603,10 +631,10 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
       }
     }
   }
-  /* contacts: every non-plane geom against every plane geom (arena vs animat, mjcf.py:251-267) */
+  /* contacts: every animat geom against every ground geom, plane or heightfield (arena vs animat, mjcf.py:251-267) */
   for (int p = 0; p < m->ngeom; p++) {
-    if (m->geom_type[p] != FMJ_GEOM_PLANE) continue;
-    for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] != FMJ_GEOM_PLANE) collide_plane(m, w, p, g, warn);
+    if (m->geom_type[p] != FMJ_GEOM_PLANE && m->geom_type[p] != FMJ_GEOM_HFIELD) continue;
+    for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD) collide_plane(m, w, p, g, warn);
   }
   double* jacp = dalloc(3 * nv);
   for (int c = 0; c < w->ncon; c++) {

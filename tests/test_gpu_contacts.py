@@ -433,3 +433,123 @@ def test_create_refuses_more_rows_than_the_solver_holds(oracle):
     m.max_contacts = 48                    # 2 + 192 = 194 rows: refused
     with pytest.raises(_lib.FmjError, match='constraint rows'):
         BatchedPhysics(m, 2)
+
+
+def _terrain(seed=0, nr=17, nc=33, rx=0.8, ry=0.4, zt=0.03):
+    """Smooth random bumps, a few centimetres high, sampled on a grid."""
+    rng = np.random.default_rng(seed)
+    xs = np.linspace(-rx, rx, nc); ys = np.linspace(-ry, ry, nr)
+    z = np.zeros((nr, nc))
+    for _ in range(6):
+        kx, ky, ph = rng.uniform(3, 9), rng.uniform(3, 9), rng.uniform(0, 6.28)
+        z += rng.uniform(0.2, 1.0)*np.sin(kx*xs[None, :] + ph)*np.cos(ky*ys[:, None] - ph)
+    return z/np.abs(z).max(), (rx, ry, zt, 0.1)
+
+
+def _hfield_walker(spawn_z=0.075):
+    """salamander33 with its capsules / foot spheres over a heightfield instead of the plane."""
+    from farms_mujoco_amd.model import salamander33
+    import farms_mujoco_amd.model as mm
+    b_ref = salamander33(contacts=True, limits=True, spawn_z=spawn_z)
+    # rebuild through the builder API: same animat, heightfield arena
+    b = mm.ModelBuilder('salamander33_hf', timestep=1e-3)
+    m = b_ref
+    for i in range(1, m.nbody):
+        j = int(m.body_jntadr[i])
+        kw = dict(pos=m.body_pos[i], quat=m.body_quat[i], mass=m.body_mass[i], ipos=m.body_ipos[i], inertia=m.body_inertia[i], iquat=m.body_iquat[i])
+        if j < 0:
+            b.add_body(m.body_names[i], m.body_names[m.body_parentid[i]], **kw)
+        elif m.jnt_type[j] == 0:
+            b.add_body(m.body_names[i], 'world', joint='free', **kw)
+        else:
+            b.add_body(m.body_names[i], m.body_names[m.body_parentid[i]], joint='hinge', jname=m.joint_names[j], axis=m.jnt_axis[j],
+                       damping=m.dof_damping[m.jnt_dofadr[j]], limited=bool(m.jnt_limited[j]), range=m.jnt_range[j], **kw)
+    for g in range(m.ngeom):
+        if m.geom_type[g] != 0:
+            b.add_geom(m.body_names[m.geom_bodyid[g]], int(m.geom_type[g]), m.geom_size[g], pos=m.geom_pos[g], quat=m.geom_quat[g],
+                       friction=m.geom_friction[g])
+    data, size = _terrain()
+    b.add_hfield(data, size, pos=(0.4, 0.0, 0.0))
+    b.options['max_contacts'] = 32
+    for a in range(m.nu):
+        if m.actuator_tags[a] == 'position':
+            b.add_position_actuator(m.joint_names[m.actuator_jntid[a]], kp=m.actuator_gain[a])
+    return b.compile()
+
+
+def test_heightfield_contacts_match_oracle(oracle):
+    """SURVEY 8 f4, the heightfield part (reference task.py:108-123, mjcf.py:486-522), met as the plane of the grid
+    triangle under each candidate point: contact lists (positions, normals that differ from contact to contact, geom
+    ids), contact forces and the state after a drop onto bumpy terrain match the oracle."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _hfield_walker()
+    n, T = 8, 80
+    rng = np.random.default_rng(12)
+    qpos = np.tile(m.qpos0, (n, 1))
+    qpos[:, 0] += rng.uniform(-0.1, 0.1, n); qpos[:, 1] += rng.uniform(-0.1, 0.1, n); qpos[:, 2] = 0.02 + 0.02*rng.uniform(size=n)
+    qpos[:, 7:] += rng.uniform(-0.2, 0.2, (n, m.nq - 7))
+    qvel = 0.02*rng.normal(size=(n, m.nv))
+    phys = BatchedPhysics(m, n)
+    q32, v32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref) and ncon_ref.max() >= 4 and ncon_ref.sum() >= 16
+    hf = int(np.nonzero(m.geom_type == 1)[0][0])
+    normals = []
+    for e in range(n):
+        fd = fds[e]
+        got = d.contact.cpu().numpy()[e, :fd['ncon']]
+        con = oracle.contacts_from_hip(got)
+        assert np.all(con[:, 15] == hf) and np.array_equal(con[:, 16], fd['contact'][:fd['ncon'], 16])
+        assert np.allclose(got[:, :3], fd['contact'][:fd['ncon'], :3], atol=2e-6)           # positions
+        assert np.allclose(got[:, 3:12], fd['contact'][:fd['ncon'], 3:12], atol=2e-5)       # frames
+        f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4)
+        assert np.allclose(got[:, 12], f.sum(1), rtol=2e-2, atol=3e-4)
+        normals.append(got[:, 3:6])
+    normals = np.concatenate(normals)
+    assert np.abs(normals[:, :2]).max() > 0.05 and np.ptp(normals[:, 0]) > 0.05         # the terrain really is bumpy
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+    for k, tol in (('xpos', 2e-6), ('qvel', 2e-3), ('qpos', 1e-5)):
+        assert _relerr(getattr(d, k).cpu().numpy(), ref[k]) < tol, (k, _relerr(getattr(d, k).cpu().numpy(), ref[k]))
+    phys.step(T - 1)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=T, n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    e = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print('heightfield drop: qpos abs err per env after', T, 'steps', e)
+    assert e.max() < 5e-3 and np.median(e) < 1e-3
+    assert float(d.qpos[:, 2].min()) > -0.03                                             # nobody fell through the terrain
+
+
+def test_flat_heightfield_equals_plane_on_the_gpu(oracle):
+    """A constant heightfield and the plane at the same height give the same rollout (to rounding: the distance is
+    formed differently)."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from farms_mujoco_amd.model import ModelBuilder, GEOM_BOX, GEOM_PLANE
+    def build(kind):
+        b = ModelBuilder('boxg', timestep=1e-3)
+        b.options['max_contacts'] = 8
+        b.add_body('trunk', pos=(0.02, -0.01, 0.03), mass=0.5, inertia=(2e-4, 6e-4, 7e-4), joint='free')
+        b.add_geom('trunk', GEOM_BOX, (0.06, 0.03, 0.015), friction=(0.8, 0, 0))
+        if kind == 'plane':
+            b.add_geom('world', GEOM_PLANE, (0, 0, 0), pos=(0, 0, 0.01))
+        else:
+            b.add_hfield(np.full((4, 6), 0.5), (0.5, 0.4, 0.02, 0.1))
+        return b.compile()
+    outs = []
+    for kind in ('plane', 'hfield'):
+        m = build(kind)
+        phys = BatchedPhysics(m, 3)
+        q = np.tile(m.qpos0, (3, 1)); q[:, 3:7] = [0.995, 0.05, 0.08, 0.0]; q[:, 3:7] /= np.linalg.norm(q[0, 3:7])
+        _set(phys, q, np.zeros((3, m.nv)))
+        phys.step(150)
+        torch.cuda.synchronize()
+        assert int(phys.data.status.abs().sum()) == 0 and int(phys.data.ncon.min()) >= 3
+        outs.append(phys.data.qpos.cpu().numpy())
+    assert np.abs(outs[0] - outs[1]).max() < 2e-4

@@ -147,3 +147,81 @@ def test_contacts2data_known_answers(oracle):
     assert np.allclose(rows[4, 6:9], 2*F1/4) and np.allclose(rows[4, 9:12], np.array([3, 0, 0])/2.0)
     # no contacts: rows are zero (no division by the zero norm sum, sensors.pyx:85)
     assert np.all(oracle.contacts2data(con, [0], g2d, 5) == 0.0)
+
+
+def _hfield_ball(data, size, pos=(0, 0, 0), quat=(1, 0, 0, 0), r=0.05, z=0.0, xy=(0.0, 0.0), mu=1.0):
+    b = ModelBuilder('ballh', timestep=1e-3)
+    I = 0.4*0.5*r*r
+    b.add_body('ball', 'world', pos=(xy[0], xy[1], z), mass=0.5, inertia=(I, I, I), joint='free')
+    b.add_geom('ball', GEOM_SPHERE, (r,), friction=(mu, 0, 0))
+    b.add_hfield(data, size, pos=pos, quat=quat)
+    b.options['max_contacts'] = 4
+    return b.compile()
+
+
+def test_heightfield_flat_equals_plane(oracle):
+    """A heightfield with constant data is the plane z = data * size_z (+ the geom's position): same contact, same force."""
+    r = 0.05
+    hf = _hfield_ball(np.full((5, 7), 0.25), (1.0, 0.5, 0.2, 0.1), pos=(0.1, -0.2, 0.3), z=0.3 + 0.05 + r - 1e-3)
+    fd = oracle.forward_debug(hf, hf.qpos0, np.zeros(6))
+    assert fd['ncon'] == 1
+    assert np.allclose(fd['contact'][0, 3:6], [0, 0, 1]) and abs(fd['contact'][0, 17] + 1e-3) < 1e-12
+    assert fd['contact'][0, 15] == 0 and fd['contact'][0, 16] == 1          # geom1 = the heightfield (world geoms first)
+    pl = _ball(r=r)
+    q = pl.qpos0.copy(); q[2] = r - 1e-3
+    fp = oracle.forward_debug(pl, q, np.zeros(6))
+    assert np.allclose(fd['efc_force'][:4], fp['efc_force'][:4], rtol=1e-12)
+    # outside the grid there is no ground
+    out = _hfield_ball(np.full((5, 7), 0.25), (1.0, 0.5, 0.2, 0.1), z=-1.0, xy=(1.2, 0.0))
+    assert oracle.forward_debug(out, out.qpos0, np.zeros(6))['ncon'] == 0
+
+
+def test_heightfield_ramp_normal_and_distance(oracle):
+    """A linear ramp z = a x + b y sampled on the grid is reproduced exactly by the triangle planes: contact normal =
+    (-a, -b, 1)/|.|, distance = n_z (z_c - z_ramp) - r, in both triangles of a cell and under a rotated / shifted frame."""
+    a, b_, r = 0.3, -0.2, 0.04
+    nr, nc, rx, ry, zt = 6, 9, 0.8, 0.5, 0.5
+    xs = np.linspace(-rx, rx, nc); ys = np.linspace(-ry, ry, nr)
+    data = (a*xs[None, :] + b_*ys[:, None])/zt
+    n_exp = np.array([-a, -b_, 1.0]); n_exp /= np.linalg.norm(n_exp)
+    for xy in ((0.13, 0.02), (0.02, 0.09), (-0.41, 0.33)):                  # lower-right and upper-left triangles
+        zc = a*xy[0] + b_*xy[1] + 0.03
+        m = _hfield_ball(data, (rx, ry, zt, 0.1), z=zc, xy=xy, r=r)
+        fd = oracle.forward_debug(m, m.qpos0, np.zeros(6))
+        assert fd['ncon'] == 1
+        assert np.allclose(fd['contact'][0, 3:6], n_exp, atol=1e-12)
+        assert abs(fd['contact'][0, 17] - (n_exp[2]*0.03 - r)) < 1e-12
+        assert np.allclose(fd['contact'][0, :3], np.array([xy[0], xy[1], zc]) - n_exp*(r + 0.5*fd['contact'][0, 17]), atol=1e-12)
+    # the same ramp turned 90 degrees about z and lifted: the normal turns with it
+    c, s = np.cos(np.pi/4), np.sin(np.pi/4)
+    m = _hfield_ball(data, (rx, ry, zt, 0.1), pos=(0, 0, 0.2), quat=(c, 0, 0, s), z=0.2 + 0.02, xy=(0.0, 0.0), r=r)
+    fd = oracle.forward_debug(m, m.qpos0, np.zeros(6))
+    Rz = np.array([[0, -1, 0], [1, 0, 0], [0, 0, 1.0]])
+    assert np.allclose(fd['contact'][0, 3:6], Rz @ n_exp, atol=1e-12)
+
+
+def test_box_settles_on_heightfield_slope(oracle):
+    """A box dropped flat onto a gentle ramp (friction 1) comes to rest on it: its four lower corners touch, the contact
+    forces balance gravity and the box has taken the slope's inclination."""
+    from farms_mujoco_amd.model import GEOM_BOX
+    a = 0.1
+    nr, nc, rx, ry, zt = 5, 11, 0.5, 0.3, 0.25
+    xs = np.linspace(-rx, rx, nc)
+    data = np.tile((a*xs)[None, :]/zt, (nr, 1))
+    b = ModelBuilder('boxh', timestep=1e-3)
+    b.add_body('p', 'world', pos=(0.03, 0.01, 0.035), mass=0.4, inertia=(4e-4, 4e-4, 4e-4), joint='free')
+    b.add_geom('p', GEOM_BOX, (0.05, 0.03, 0.02), friction=(1.0, 0, 0))
+    b.add_hfield(data, (rx, ry, zt, 0.1))
+    b.options['max_contacts'] = 8
+    m = b.compile()
+    o = oracle.step(m, m.qpos0[None], np.zeros((1, 6)), n_steps=2500)
+    assert abs(o['qvel'][0]).max() < 2e-3
+    fd = oracle.forward_debug(m, o['qpos'][0], o['qvel'][0])
+    assert fd['ncon'] == 4
+    f = sum(fd['contact'][c, 12]*fd['contact'][c, 3:6] + fd['contact'][c, 13]*fd['contact'][c, 6:9] + fd['contact'][c, 14]*fd['contact'][c, 9:12]
+            for c in range(4))
+    assert abs(f[2] - 0.4*9.81) < 0.03*0.4*9.81 and abs(f[0]) < 0.05*0.4*9.81
+    n_exp = np.array([-a, 0, 1.0])/np.hypot(a, 1.0)
+    assert np.allclose(fd['contact'][:4, 3:6], n_exp, atol=1e-12)
+    from farms_mujoco_amd.model import quat2mat
+    assert abs(quat2mat(o['qpos'][0, 3:7])[:, 2] @ n_exp - 1.0) < 1e-3      # box z axis along the slope normal

@@ -204,3 +204,41 @@ def test_cylinder_collision_maps_to_radius_and_half_length(tmp_path, sdf_path):
     m = sdf2model(ModelSDF.read(str(p))[0], animat_options=_options(str(p)), use_collisions=True, plane=True)
     g = [i for i in range(m.ngeom) if m.geom_type[i] == GEOM_CYLINDER]
     assert len(g) == 1 and np.allclose(m.geom_size[g[0]][:2], [0.02, 0.05])
+
+
+ARENA_SDF = """<?xml version="1.0"?>
+<sdf version="1.6">
+  <model name="arena">
+    <link name="terrain">
+      <pose>0 0 0 0 0 0</pose>
+      <collision name="terrain_col"><pose>0 0 0 0 0 0</pose>
+        <geometry><heightmap><uri>terrain.png</uri><size>2.0 1.0 0.2</size></heightmap></geometry></collision>
+    </link>
+  </model>
+</sdf>
+"""
+
+
+def test_arena_heightmap_compiles_to_heightfield(sdf_path, tmp_path):
+    """Arena SDF with a heightmap (reference mjcf.py:486-522, :1195-1212; task.py:108-115): the image is normalised,
+    flipped to Cartesian rows and stored as 2 (image - 0.5); the asset size is (x/2, y/2, z/2, z) scaled by units.meters;
+    ground_height lifts the arena; the animat gets its collision geoms."""
+    from farms_mujoco_amd.io.png import imwrite_gray
+    from farms_mujoco_amd.model import GEOM_HFIELD
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 65535, (6, 9)).astype(np.uint16)
+    imwrite_gray(str(tmp_path/'terrain.png'), img)
+    (tmp_path/'arena.sdf').write_text(ARENA_SDF)
+    units = SimulationUnitScaling(meters=2.0, seconds=1.0, kilograms=1.0)
+    opts = SimulationOptions(timestep=1e-3, units=units)
+    arena = ArenaOptions(sdf=str(tmp_path/'arena.sdf'), ground_height=0.05, spawn_pose=[0.1, 0, 0, 0, 0, 0])
+    m = setup_model(opts, _options(sdf_path), arena)
+    g = int(np.nonzero(m.geom_type == GEOM_HFIELD)[0][0])
+    assert m.geom_bodyid[g] == 0 and (m.hfield_nrow, m.hfield_ncol) == (6, 9)
+    assert np.allclose(m.hfield_size, [2.0, 1.0, 0.2, 0.4])                     # (x/2, y/2, z/2, z) * meters
+    want = 2*(np.flip(img.astype(float)/65535, axis=0) - 0.5)
+    assert np.allclose(m.hfield_data, want) and m.hfield_data.min() < -0.9 and m.hfield_data.max() > 0.9
+    assert np.allclose(m.geom_pos[g], [0.2, 0, 0.1])                           # (spawn + ground_height) * meters
+    assert m.max_contacts >= 32 and (m.geom_type != GEOM_HFIELD).sum() == 2   # head capsule + trunk sphere collide with it
+    c = m.as_c()
+    assert c.hfield_nrow == 6 and c.hfield_ncol == 9 and abs(c.hfield_data[3] - want.ravel()[3]) < 1e-15
