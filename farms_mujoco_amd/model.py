@@ -116,6 +116,7 @@ class ModelBuilder:
                                           np.zeros(3), np.array([1., 0, 0, 0]), np.zeros(3))]
         self.actuators: List[dict] = []
         self.hfield: Optional[dict] = None
+        self.pairs: List[dict] = []
         self.options = dict(solver_iterations=50, max_contacts=0, impratio=1.0, solver_tolerance=1e-8)
 
     def body_id(self, name: str) -> int:
@@ -190,6 +191,12 @@ class ModelBuilder:
         self.hfield = dict(data=data, size=np.asarray(size, float).reshape(4))
         self.add_geom('world', GEOM_HFIELD, (0, 0, 0), pos=pos, quat=quat, friction=friction, solref=solref, solimp=solimp)
 
+    def add_contact_pair(self, body1, body2, friction=0.0, solref=DEFAULT_SOLREF, solimp=DEFAULT_SOLIMP):
+        """Explicit contact pairs between every collision geom of ``body1`` and every one of ``body2`` (MJCF contact/pair,
+        condim 3, the loop of reference mjcf.py:1012-1033 over morphology.self_collisions).  Resolved at compile()."""
+        self.pairs.append(dict(body1=body1, body2=body2, friction=float(friction), solref=np.asarray(solref, float),
+                               solimp=np.asarray(solimp, float)))
+
     def add_joint_actuators(self, joint_name, kp=0.0, kv=0.0, forcerange=None, pos_limits=None, vel_limits=None):
         """The position / velocity / motor triple of reference mjcf.py:819-866.  ``forcerange`` = the motor's
         ``limits_torque`` applied to all three (:855-865); ``pos_limits`` / ``vel_limits`` = dict(ctrllimited, ctrlrange,
@@ -237,6 +244,7 @@ _CMODEL_FIELDS = (
         [(n, _D) for n in ('geom_size', 'geom_pos', 'geom_quat', 'geom_friction', 'geom_solref', 'geom_solimp',
                            'body_invweight0')] +
         [('hfield_nrow', ctypes.c_int32), ('hfield_ncol', ctypes.c_int32), ('hfield_size', ctypes.c_double*4), ('hfield_data', _D)] +
+        [('npair', ctypes.c_int32), ('pair_geom1', _I), ('pair_geom2', _I), ('pair_friction', _D), ('pair_solref', _D), ('pair_solimp', _D)] +
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
          ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)]
 )
@@ -250,12 +258,12 @@ class _CModel(ctypes.Structure):
 _INT_FIELDS = ('body_parentid', 'body_rootid', 'body_jntadr', 'body_dofadr', 'body_dofnum', 'jnt_type',
                'jnt_qposadr', 'jnt_dofadr', 'jnt_bodyid', 'jnt_limited', 'dof_bodyid', 'dof_jntid',
                'dof_parentid', 'dof_Madr', 'actuator_jntid', 'actuator_ctrllimited', 'actuator_forcelimited',
-               'geom_type', 'geom_bodyid')
+               'geom_type', 'geom_bodyid', 'pair_geom1', 'pair_geom2')
 _DBL_FIELDS = ('body_pos', 'body_quat', 'body_ipos', 'body_iquat', 'body_mass', 'body_inertia', 'jnt_pos',
                'jnt_axis', 'jnt_stiffness', 'jnt_range', 'jnt_solref', 'jnt_solimp', 'jnt_margin', 'qpos0',
                'dof_armature', 'dof_damping', 'dof_invweight0', 'actuator_gain', 'actuator_bias',
                'actuator_ctrlrange', 'actuator_forcerange', 'geom_size', 'geom_pos', 'geom_quat',
-               'geom_friction', 'geom_solref', 'geom_solimp', 'body_invweight0')
+               'geom_friction', 'geom_solref', 'geom_solimp', 'body_invweight0', 'pair_friction', 'pair_solref', 'pair_solimp')
 
 
 class Model:
@@ -409,6 +417,18 @@ class Model:
         m.geom_friction = np.array([g['friction'] for _, g in geoms], float).reshape(-1, 3)
         m.geom_solref = np.array([g['solref'] for _, g in geoms], float).reshape(-1, 2)
         m.geom_solimp = np.array([g['solimp'] for _, g in geoms], float).reshape(-1, 5)
+        # explicit geom pairs: every geom of body1 x every geom of body2, in the order the pairs were added
+        pg1, pg2, pfr, psr, psi = [], [], [], [], []
+        for pr in b.pairs:
+            b1 = new_of_old[b.body_id(pr['body1'])] if not isinstance(pr['body1'], int) else new_of_old[pr['body1']]
+            b2 = new_of_old[b.body_id(pr['body2'])] if not isinstance(pr['body2'], int) else new_of_old[pr['body2']]
+            for ga in [gi for gi, (bi, _) in enumerate(geoms) if bi == b1]:
+                for gb in [gi for gi, (bi, _) in enumerate(geoms) if bi == b2]:
+                    pg1.append(ga); pg2.append(gb); pfr.append(pr['friction']); psr.append(pr['solref']); psi.append(pr['solimp'])
+        m.npair = len(pg1)
+        m.pair_geom1 = np.array(pg1, np.int32); m.pair_geom2 = np.array(pg2, np.int32)
+        m.pair_friction = np.array(pfr, float)
+        m.pair_solref = np.array(psr, float).reshape(-1, 2); m.pair_solimp = np.array(psi, float).reshape(-1, 5)
         m.hfield_nrow, m.hfield_ncol = (b.hfield['data'].shape if b.hfield is not None else (0, 0))
         m.hfield_size = b.hfield['size'].copy() if b.hfield is not None else np.zeros(4)
         m.hfield_data = b.hfield['data'].copy() if b.hfield is not None else None
@@ -484,6 +504,7 @@ class Model:
         c.abi_version = ABI_VERSION
         for n in ('nbody', 'njnt', 'nq', 'nv', 'nu', 'ngeom', 'nM', 'solver_iterations', 'max_contacts'):
             setattr(c, n, int(getattr(self, n)))
+        c.npair = int(getattr(self, 'npair', 0))
         c.timestep = self.timestep
         c.gravity = (ctypes.c_double*3)(*self.gravity)
         c.impratio = self.impratio

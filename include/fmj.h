@@ -151,6 +151,16 @@ typedef struct fmj_model {
   int32_t hfield_nrow, hfield_ncol;
   double hfield_size[4];
   const double* hfield_data;    /* [nrow*ncol] or NULL */
+  /* explicit contact pairs between animat geoms (MJCF contact/pair, condim 3; the reference emits one per pair of
+   * collision shapes of every morphology.self_collisions link pair, friction 0: mjcf.py:1012-1033).  Supported shapes:
+   * sphere and capsule; one contact per pair, at the closest points of the two segments.  A sliding friction below
+   * MuJoCo's mjMINMU = 1e-5 is raised to it. */
+  int32_t npair;
+  const int32_t* pair_geom1;    /* [npair] */
+  const int32_t* pair_geom2;    /* [npair] */
+  const double* pair_friction;  /* [npair] */
+  const double* pair_solref;    /* [npair,2] */
+  const double* pair_solimp;    /* [npair,5] */
 
   /* constraint solver options (mjcf.py:1330-1403) */
   int32_t solver_iterations;

@@ -121,7 +121,7 @@ typedef struct ws_t {
   double *efc_MiJT;
   int *efc_type, *efc_id;
   /* contacts */
-  int *con_geom, *con_plane; double *con_pos, *con_frame, *con_dist, *con_mu; int *con_efc;
+  int *con_geom, *con_plane, *con_pair; double *con_pos, *con_frame, *con_dist, *con_mu; int *con_efc;   /* geom2, geom1, explicit pair or -1 */
   double *jointlimitfrc;
   double meaninertia;
   int disable_actuation;      /* mj_forward with mjDSBL_ACTUATION (what dm_control runs after physics.reset, task.py:137) */
@@ -158,6 +158,7 @@ static ws_t* ws_new(const fmj_model* m) {
   w->con_geom = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
   w->con_efc = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
   w->con_plane = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
+  w->con_pair = (int*)calloc(maxcon ? maxcon : 1, sizeof(int));
   w->con_pos = dalloc(3 * maxcon); w->con_frame = dalloc(9 * maxcon);
   w->con_dist = dalloc(maxcon); w->con_mu = dalloc(maxcon);
   w->jointlimitfrc = dalloc(nj);
@@ -173,7 +174,7 @@ static void ws_free(ws_t* w) {
                   &w->efc_aref, &w->efc_b, &w->efc_AR, &w->efc_force, &w->efc_diagApprox,
                   &w->efc_MiJT, &w->con_pos, &w->con_frame, &w->con_dist, &w->con_mu, &w->jointlimitfrc};
   for (size_t i = 0; i < sizeof p / sizeof p[0]; i++) free(*p[i]);
-  free(w->efc_type); free(w->efc_id); free(w->con_geom); free(w->con_efc); free(w->con_plane);
+  free(w->efc_type); free(w->efc_id); free(w->con_geom); free(w->con_efc); free(w->con_plane); free(w->con_pair);
   free(w);
 }
 
@@ -482,7 +483,7 @@ static int add_efc(const fmj_model* m, ws_t* w, const double* jrow, double pos, 
 static void add_contact(const fmj_model* m, ws_t* w, int p, int g, const double* pos, const double* n, double dist, double mu, int* warn) {
   if (w->ncon >= m->max_contacts) { *warn |= FMJ_WARN_CONTACTFULL; return; }
   int c = w->ncon++;
-  w->con_geom[c] = g; w->con_plane[c] = p; w->con_dist[c] = dist; w->con_mu[c] = mu;
+  w->con_geom[c] = g; w->con_plane[c] = p; w->con_pair[c] = -1; w->con_dist[c] = dist; w->con_mu[c] = mu;
   memcpy(w->con_pos + 3 * c, pos, 3 * sizeof(double));
   /* frame: x = normal, y/z = tangents (mju_makeFrame) */
   double* f = w->con_frame + 9 * c;
@@ -613,6 +614,58 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
   }
 }
 
+/* closest points of two segments c1 +- h1 a1 and c2 +- h2 a2 (unit axes): parameters s, t along the axes (the classic
+ * clamped solution; parallel segments take the midpoint of their overlap) */
+static void segment_closest(const double* c1, const double* a1, double h1, const double* c2, const double* a2, double h2,
+                            double* s_out, double* t_out) {
+  double d[3] = {c1[0] - c2[0], c1[1] - c2[1], c1[2] - c2[2]};
+  double b = dotn(a1, a2, 3), da1 = dotn(d, a1, 3), da2 = dotn(d, a2, 3);
+  double det = 1.0 - b * b, s, t;
+  if (det > 1e-9) {
+    s = (b * da2 - da1) / det;
+    s = fmin(fmax(s, -h1), h1);
+  } else {                                  /* parallel: centre of the overlap of the two parameter intervals */
+    double lo = fmax(-h1, -da1 - h2), hi = fmin(h1, -da1 + h2);       /* c2's interval seen on axis 1: centre -da1 */
+    s = lo <= hi ? 0.5 * (lo + hi) : (fabs(lo - h1) < fabs(hi + h1) ? h1 : -h1);
+    s = fmin(fmax(s, -h1), h1);
+  }
+  t = b * s + da2; t = fmin(fmax(t, -h2), h2);
+  s = b * t - da1; s = fmin(fmax(s, -h1), h1);
+  *s_out = s; *t_out = t;
+}
+
+/* explicit pair 'pr' between sphere / capsule geoms g1, g2: one contact at the closest points of their segments, normal
+ * from geom1 to geom2 (mjContact convention), position midway between the surfaces */
+static void collide_pair(const fmj_model* m, ws_t* w, int pr, int* warn) {
+  int g[2] = {m->pair_geom1[pr], m->pair_geom2[pr]};
+  double cen[2][3], ax[2][3], half[2], rad[2];
+  for (int k = 0; k < 2; k++) {
+    int gb = m->geom_bodyid[g[k]];
+    double gq[4], gm[9], v[3];
+    mul_quat(gq, w->xquat + 4 * gb, m->geom_quat + 4 * g[k]);
+    rot_vec_quat(v, m->geom_pos + 3 * g[k], w->xquat + 4 * gb);
+    for (int i = 0; i < 3; i++) cen[k][i] = w->xpos[3 * gb + i] + v[i];
+    quat2mat(gm, gq);
+    for (int i = 0; i < 3; i++) ax[k][i] = gm[3 * i + 2];
+    rad[k] = m->geom_size[3 * g[k]];
+    half[k] = m->geom_type[g[k]] == FMJ_GEOM_CAPSULE ? m->geom_size[3 * g[k] + 1] : 0.0;
+  }
+  double s, t;
+  segment_closest(cen[0], ax[0], half[0], cen[1], ax[1], half[1], &s, &t);
+  double p1[3], p2[3], n[3];
+  for (int i = 0; i < 3; i++) { p1[i] = cen[0][i] + s * ax[0][i]; p2[i] = cen[1][i] + t * ax[1][i]; n[i] = p2[i] - p1[i]; }
+  double len = sqrt(dotn(n, n, 3));
+  double dist = len - rad[0] - rad[1];
+  if (!(dist < 0)) return;                 /* margin = 0 */
+  if (len < MINVAL) { n[0] = 0; n[1] = 0; n[2] = 1; } else for (int i = 0; i < 3; i++) n[i] /= len;
+  double pos[3];
+  for (int i = 0; i < 3; i++) pos[i] = p1[i] + n[i] * (rad[0] + 0.5 * dist);
+  double mu = fmax(m->pair_friction[pr], 1e-5);        /* mjMINMU */
+  if (w->ncon >= m->max_contacts) { *warn |= FMJ_WARN_CONTACTFULL; return; }
+  add_contact(m, w, g[0], g[1], pos, n, dist, mu, warn);
+  w->con_pair[w->ncon - 1] = pr;
+}
+
 static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, int* warn) {
   int nv = m->nv;
   w->nefc = 0; w->ncon = 0;
@@ -636,10 +689,16 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
     if (m->geom_type[p] != FMJ_GEOM_PLANE && m->geom_type[p] != FMJ_GEOM_HFIELD) continue;
     for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD) collide_plane(m, w, p, g, warn);
   }
+  for (int pr = 0; pr < m->npair; pr++) collide_pair(m, w, pr, warn);      /* after the ground contacts */
   double* jacp = dalloc(3 * nv);
+  double* jacp1 = dalloc(3 * nv);
   for (int c = 0; c < w->ncon; c++) {
-    int g = w->con_geom[c], b = m->geom_bodyid[g];
+    int g = w->con_geom[c], b = m->geom_bodyid[g], b1 = m->geom_bodyid[w->con_plane[c]];
     jac_point(m, w, jacp, NULL, w->con_pos + 3 * c, b);
+    if (b1 > 0) {                          /* jacdif = J(body2) - J(body1): both bodies move in a self-collision */
+      jac_point(m, w, jacp1, NULL, w->con_pos + 3 * c, b1);
+      for (int i = 0; i < 3 * nv; i++) jacp[i] -= jacp1[i];
+    }
     /* contact-frame Jacobian of (geom body - plane body); plane is static => J = -(-J_b)?
        MuJoCo: jacdif = J(body2) - J(body1), geom1 = plane, geom2 = animat geom. */
     const double* f = w->con_frame + 9 * c;
@@ -663,11 +722,12 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
     }
     if (buf != jn) free(buf);
   }
-  free(jacp);
+  free(jacp); free(jacp1);
   /* impedance, R, aref (mj_makeImpedance, mj_referenceConstraint) */
   for (int e = 0; e < w->nefc; e++) {
     const double *solref, *solimp;
     if (w->efc_type[e] == EFC_LIMIT) { solref = m->jnt_solref + 2 * w->efc_id[e]; solimp = m->jnt_solimp + 5 * w->efc_id[e]; }
+    else if (w->con_pair[w->efc_id[e]] >= 0) { int pr = w->con_pair[w->efc_id[e]]; solref = m->pair_solref + 2 * pr; solimp = m->pair_solimp + 5 * pr; }
     else { int g = w->con_geom[w->efc_id[e]]; solref = m->geom_solref + 2 * g; solimp = m->geom_solimp + 5 * g; }
     double imp; get_impedance(solimp, w->efc_pos[e], w->efc_margin[e], &imp);
     double dmax = fmin(fmax(solimp[1], MINIMP), MAXIMP);

@@ -225,3 +225,74 @@ def test_box_settles_on_heightfield_slope(oracle):
     assert np.allclose(fd['contact'][:4, 3:6], n_exp, atol=1e-12)
     from farms_mujoco_amd.model import quat2mat
     assert abs(quat2mat(o['qpos'][0, 3:7])[:, 2] @ n_exp - 1.0) < 1e-3      # box z axis along the slope normal
+
+
+def _scissors(theta=0.35, r=0.03, L=0.2, friction=0.0, capsule=False):
+    """A fixed post with two equal arms hinged about z at the origin, tip spheres (or capsules along the arms) in an
+    explicit contact pair: the arms close like scissors."""
+    from farms_mujoco_amd.model import GEOM_CAPSULE, axisangle2quat
+    b = ModelBuilder('scissors', timestep=1e-3, gravity=(0, 0, 0))
+    b.add_body('post', 'world', pos=(0, 0, 0.5), mass=1.0, inertia=(1e-3, 1e-3, 1e-3))
+    for name, sgn in (('arm_a', +1), ('arm_b', -1)):
+        b.add_body(name, 'post', mass=0.2, ipos=(L/2, 0, 0), inertia=(1e-5, 7e-4, 7e-4), joint='hinge', axis=(0, 0, 1), damping=1e-3,
+                   qpos0=0.0)
+        if capsule:
+            b.add_geom(name, GEOM_CAPSULE, (r, L/2), pos=(L/2, 0, 0), quat=axisangle2quat([0, 1, 0], np.pi/2))
+        else:
+            b.add_geom(name, GEOM_SPHERE, (r,), pos=(L, 0, 0))
+    b.add_contact_pair('arm_a', 'arm_b', friction=friction)
+    b.options['max_contacts'] = 4
+    m = b.compile()
+    return m, np.array([theta, -theta])
+
+
+def test_self_collision_pair_geometry_and_symmetry(oracle):
+    """Explicit contact pair between two tip spheres (reference mjcf.py:1012-1033: contact/pair, condim 3, friction 0):
+    normal from geom1 to geom2, position midway, distance = centre distance - 2 r; the contact pushes the two arms apart
+    with equal and opposite accelerations; no contact once the spheres are apart."""
+    r, L = 0.03, 0.2
+    theta = np.arcsin((r - 0.002)/L)                       # centre distance 2 (r - 0.002): 4 mm of overlap
+    m, q = _scissors(theta, r, L)
+    assert m.npair == 1 and m.pair_geom1[0] != m.pair_geom2[0]
+    fd = oracle.forward_debug(m, q, np.zeros(2))
+    assert fd['ncon'] == 1 and fd['nefc'] == 4
+    ct = fd['contact'][0]
+    assert np.allclose(ct[3:6], [0, -1, 0], atol=1e-12)                            # from arm_a's sphere (y > 0) to arm_b's
+    assert abs(ct[17] + 0.004) < 1e-12 and np.allclose(ct[:3], [L*np.cos(theta), 0, 0.5], atol=1e-12)
+    assert ct[15] == m.pair_geom1[0] and ct[16] == m.pair_geom2[0]
+    assert ct[12] > 0 and np.all(np.abs(ct[13:15]) <= 1.0001e-5*ct[12])          # pushing; friction bounded by mjMINMU * normal force
+    assert fd['qacc'][0] > 0 and abs(fd['qacc'][0] + fd['qacc'][1]) < 1e-9*abs(fd['qacc'][0])
+    m2, q2 = _scissors(theta*1.3, r, L)
+    assert oracle.forward_debug(m2, q2, np.zeros(2))['ncon'] == 0
+    # rolled forward the arms separate and stay apart (soft contact, no gravity, light damping)
+    o = oracle.step(m, q[None], np.zeros((1, 2)), n_steps=300)
+    assert o['qpos'][0, 0] > theta and abs(o['qpos'][0, 0] + o['qpos'][0, 1]) < 1e-9
+    assert oracle.forward_debug(m, o['qpos'][0], o['qvel'][0])['ncon'] == 0
+
+
+def test_self_collision_capsules_closest_points(oracle):
+    """Capsule - capsule pair: one contact at the closest points of the two segments (crossing arms touch near the
+    hinge end of their overlap; parallel arms in the middle of it)."""
+    r, L = 0.03, 0.2
+    m, q = _scissors(0.2, r, L, capsule=True)
+    fd = oracle.forward_debug(m, q, np.zeros(2))
+    assert fd['ncon'] == 1
+    ct = fd['contact'][0]
+    # the segments start at the common hinge: closest points are the segment starts (distance 0): full overlap 2 r
+    assert abs(ct[17] + 2*r) < 1e-9 and np.allclose(ct[:3], [0, 0, 0.5], atol=1e-9)
+    # parallel capsules side by side
+    from farms_mujoco_amd.model import GEOM_CAPSULE, axisangle2quat
+    b = ModelBuilder('par', timestep=1e-3, gravity=(0, 0, 0))
+    b.add_body('post', 'world', pos=(0, 0, 0.5), mass=1.0, inertia=(1e-3, 1e-3, 1e-3))
+    for name, y, x0 in (('a', 0.0, 0.0), ('b', 0.05, 0.1)):
+        b.add_body(name, 'post', pos=(x0, y, 0), mass=0.2, inertia=(1e-5, 7e-4, 7e-4), joint='slide', axis=(0, 1, 0))
+        b.add_geom(name, GEOM_CAPSULE, (r, L/2), quat=axisangle2quat([0, 1, 0], np.pi/2))
+    b.add_contact_pair('a', 'b')
+    b.options['max_contacts'] = 2
+    mp = b.compile()
+    fd = oracle.forward_debug(mp, np.zeros(2), np.zeros(2))
+    assert fd['ncon'] == 1
+    ct = fd['contact'][0]
+    assert abs(ct[17] - (0.05 - 2*r)) < 1e-12 and np.allclose(ct[3:6], [0, 1, 0], atol=1e-12)
+    assert abs(ct[0] - 0.05) < 1e-9                       # middle of the overlap [0.0, 0.1] of the two segments
+    assert fd['qacc'][1] > 0 > fd['qacc'][0] and abs(fd['qacc'][0] + fd['qacc'][1]) < 1e-9*abs(fd['qacc'][1])
