@@ -74,6 +74,9 @@ struct DevModel {
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
   const float* hf_data;       // [hf_nrow][hf_ncol] heightfield samples (one heightfield per model)
   int hf_nrow, hf_ncol;
+  int npair, nfl;             // explicit geom pairs; fork rows (4 per pair contact) the LDS path provides
+  const float4* qtab;         // [npair][QT_STRIDE]: (geom1, geom2 bits, friction, -), (solref, solimp 0..1), (solimp 2..4, -)
+  float* cons_zf;             // [n_envs][maxefc][rs] fork parts of the compact rows (HBM path)
   float* cons_rows;           // [n_envs][maxefc][8] row parameters of envs with more rows than LDS holds
   float* cons_a;              // [n_envs][maxefc][AG_LD] their PGS matrix
   float* cons_z;              // [n_envs][maxefc][rs] their compact constraint rows
@@ -103,6 +106,7 @@ struct DevModel {
 #define AT_STRIDE 3    // per actuator (sorted by dof): prm, lim, (source index bits, -, -, -)
 #define ST_STRIDE 4    // per swimming link: c0 (force coefficients, mass), c1 (torque coefficients, height), c2 (density, rows, body), c3 (mass / density, 1 / height)
 #define GT_STRIDE 6    // per geom: info(int4), size, pos, quat, sol0, sol1
+#define QT_STRIDE 3    // per explicit geom pair
 #define PT_STRIDE 4    // per ground geom: plane (n, offset) or heightfield position; prm (friction, heightfield flag, geom id); heightfield quat; heightfield rx, ry, size z
 __device__ __forceinline__ unsigned __float_as_uint_(float f) { return (unsigned)__float_as_int(f); }
 __device__ __forceinline__ int4 as_int4(float4 v) { return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)); }
@@ -116,6 +120,7 @@ __device__ __forceinline__ int4 as_int4(float4 v) { return make_int4(__float_as_
 #define GTAB(g, k) (M.gtab[(unsigned)(g) * GT_STRIDE + (k)])
 #define GTABI(g, k) as_int4(GTAB(g, k))
 #define PTAB(p, k) (M.ptab[(unsigned)(p) * PT_STRIDE + (k)])
+#define QTAB(p, k) (M.qtab[(unsigned)(p) * QT_STRIDE + (k)])
 
 struct StepArgs {
   float* qpos; float* qvel; const float* ctrl; const float* qpos_spring; const float* xfrc_applied;
@@ -385,11 +390,13 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 struct LdsLayout {
   int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
   int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
+  int YF, CF, nfl;                                                  // explicit pairs: fork parts of their rows, fork chain per row
 };
+#define FMJ_NFL 32     // fork rows (8 pair contacts) kept on chip
 #define AG_LD 192      // row length of the global PGS matrix (three 64-lane slots)
 #define FMJ_NA 60      // constraint rows handled with one row per lane and A in registers
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
-                                                int maxcon = 0, int nvs = 0) {
+                                                int maxcon = 0, int nvs = 0, int npair = 0) {
   LdsLayout L;
   const int nmax = nb > nv ? nb : nv;
   int o = 0;
@@ -402,6 +409,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
   L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.SD = L.PO = L.AT = L.LC = L.CH = o; L.na = 0;
+  L.YF = L.CF = o; L.nfl = 0;
   const int dead = 2 * nmax * 8 + r4(nb * 12);   // T/F, V/BUF, CI: not live between the M phase and the next step
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
@@ -415,6 +423,12 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
     L.CH = o; o += r4((maxefc + 3) / 4);         // uint8 per row: last dof of the row's chain + 1
     L.na = maxefc < FMJ_NA ? maxefc : FMJ_NA;    // rows kept on chip ("small"); larger row sets live in HBM, staged through YJ
     L.EP = o; o += L.na * 8;                      // per row: -, aref, R, b, force, R0, type|id, mu
+    if (npair > 0) {
+      int nf = 4 * (npair < maxcon ? npair : maxcon);
+      L.nfl = nf < FMJ_NFL ? nf : FMJ_NFL;
+      L.YF = o; o += L.nfl * rs;                  // fork part of the rows of pair contacts (the second body's branch)
+      L.CF = o; o += r4((maxefc + 3) / 4);        // uint8 per row: last dof of the fork's chain + 1 (0: no fork)
+    }
   }
   L.CD = o; o += nv * 8;              // cdof
   L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
@@ -764,7 +778,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
-  const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride, CONS ? 1 : 0, M.maxefc, M.max_contacts, M.nvs);
+  const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride, CONS ? 1 : 0, M.maxefc, M.max_contacts, M.nvs, M.npair);
   float* T = lds + LL.P1;  float* F = T;       // T (transforms) -> W (acceleration scan) -> F (body force)
   float* V = lds + LL.P2;  float* BUF = V;     // V (velocity scan) -> BUF (I w, m v)
   float* CI = lds + LL.CI;
@@ -779,6 +793,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EPL = lds + LL.EP;  float* CT = lds + LL.CT;
   float* XS = lds + LL.XS;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
   float* PO = lds + LL.PO;  float* LC = lds + LL.LC;  float* SD = lds + LL.SD;  float* CH = lds + LL.CH;
+  float* YFL = lds + LL.YF; float* CF = lds + LL.CF;
 
   const bool isb = lane > 0 && lane < nb;
   const int bl = isb ? lane : 0;
@@ -1371,7 +1386,66 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           }
         }
       }
+      int ncg = ncon;                               // ground contacts; explicit pairs follow, in pair order (like the oracle)
+      if (M.npair) {
+        for (int p0 = 0; p0 < M.npair; p0 += 64) {
+          const int pr = p0 + lane;
+          bool hit = false; v3 pos = mk3(0.f, 0.f, 0.f), nrm = mk3(0.f, 0.f, 1.f); float dist = 0.f, mu = 0.f; int g1 = 0, g2 = 0;
+          if (pr < M.npair) {
+            const float4 q0 = QTAB(pr, 0);
+            g1 = __float_as_int(q0.x); g2 = __float_as_int(q0.y); mu = q0.z;
+            v3 cen[2], ax[2]; float half[2], rad[2];
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+              const int g = k ? g2 : g1;
+              const int4 gi = GTABI(g, 0);
+              const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
+              const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+              const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
+              cen[k] = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+              ax[k] = qrot(qmul(bqq, gqq), mk3(0.f, 0.f, 1.f));
+              rad[k] = gs.x; half[k] = gi.x == FMJ_GEOM_CAPSULE ? gs.y : 0.f;
+            }
+            // closest points of the two segments (the oracle's segment_closest)
+            const v3 d = sub3(cen[0], cen[1]);
+            const float b = dot3(ax[0], ax[1]), da1 = dot3(d, ax[0]), da2 = dot3(d, ax[1]);
+            const float det = 1.f - b * b;
+            float sp, tp;
+            if (det > 1e-9f) sp = fminf(fmaxf((b * da2 - da1) / det, -half[0]), half[0]);
+            else {
+              const float lo = fmaxf(-half[0], -da1 - half[1]), hi = fminf(half[0], -da1 + half[1]);
+              sp = lo <= hi ? 0.5f * (lo + hi) : (fabsf(lo - half[0]) < fabsf(hi + half[0]) ? half[0] : -half[0]);
+              sp = fminf(fmaxf(sp, -half[0]), half[0]);
+            }
+            tp = fminf(fmaxf(b * sp + da2, -half[1]), half[1]);
+            sp = fminf(fmaxf(b * tp - da1, -half[0]), half[0]);
+            const v3 p1 = add3(cen[0], scl3(ax[0], sp)), p2 = add3(cen[1], scl3(ax[1], tp));
+            v3 n = sub3(p2, p1);
+            const float len = sqrtf(dot3(n, n));
+            dist = len - rad[0] - rad[1];
+            hit = dist < 0.f;
+            n = len < 1e-15f ? mk3(0.f, 0.f, 1.f) : scl3(n, 1.0f / len);
+            nrm = n;
+            pos = add3(p1, scl3(n, rad[0] + 0.5f * dist));
+          }
+          const unsigned long long bk = __ballot(hit);
+          const int slot = ncon + __popcll(bk & lt);
+          ncon += __popcll(bk);
+          if (hit && slot < M.max_contacts) {
+            v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
+            t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
+            t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
+            const v3 t2 = cross(nrm, t1);
+            float* ct = CT + slot * 16;
+            *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
+            *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
+            *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
+            *(float4*)(ct + 12) = make_float4(dist, mu, __int_as_float(g2), __int_as_float(g1 | ((pr + 1) << 16)));
+          }
+        }
+      }
       if (ncon > M.max_contacts) { ncon = M.max_contacts; warn |= FMJ_WARN_CONTACTFULL; }
+      if (ncg > ncon) ncg = ncon;
       const int nefc = nlim + 4 * ncon;
       WSYNC();
       STAMP(13);  // limits + contacts
@@ -1380,15 +1454,19 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       //     dof (+1).  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
       //     Up to LL.na rows everything stays on chip ("small": the rows overlay T/F, V/BUF and CI, dead by now); with
       //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
-      if (nefc <= LL.na) {
+      const int e_p0 = nlim + 4 * ncg;              // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
+      const bool hasp = M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
+      if (nefc <= LL.na && nefc - e_p0 <= LL.nfl) {
         constexpr bool small = true;
         float* const YC = YJ;
         float* const EP = EPL;
+        float* const YF = YFL;
 #include "fmj_cons_rows.inc"
       } else {
         constexpr bool small = false;
         float* const YC = M.cons_z + (size_t)env * M.maxefc * RS;
         float* const EP = M.cons_rows + (size_t)env * M.maxefc * 8;
+        float* const YF = M.cons_zf ? M.cons_zf + (size_t)env * M.maxefc * RS : nullptr;
 #include "fmj_cons_rows.inc"
       }
     }
@@ -1696,8 +1774,20 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
     if (t == FMJ_GEOM_BOX || t == FMJ_GEOM_CYLINDER) any_box = 1;      // geoms with up to 4 contacts
   }
-  const int cons = any_limit || (nplane > 0 && m->ngeom > nplane);
-  if (cons && m->ngeom > nplane && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
+  if (m->npair < 0 || (m->npair > 0 && (!m->pair_geom1 || !m->pair_geom2 || !m->pair_friction || !m->pair_solref || !m->pair_solimp)))
+    return set_err(FMJ_ERR_ARG, "fmj_create: pair arrays missing");
+  if (m->ngeom >= 65536 || m->npair >= 32767) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: too many geoms / pairs");
+  for (int p = 0; p < m->npair; p++) {
+    const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
+    if (g1 < 0 || g1 >= m->ngeom || g2 < 0 || g2 >= m->ngeom) return set_err(FMJ_ERR_ARG, "fmj_create: pair geom out of range");
+    const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
+    if ((t1 != FMJ_GEOM_SPHERE && t1 != FMJ_GEOM_CAPSULE) || (t2 != FMJ_GEOM_SPHERE && t2 != FMJ_GEOM_CAPSULE))
+      return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: explicit contact pairs need sphere / capsule geoms");
+    if (m->geom_bodyid[g1] == m->geom_bodyid[g2]) return set_err(FMJ_ERR_ARG, "fmj_create: a contact pair joins geoms of two bodies");
+  }
+  const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
+  if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
+  if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
   if (m->body_parentid[1] != 0) return set_err(FMJ_ERR_ARG, "fmj_create: body 1 must be the root (parent = world)");
   std::vector<int> bdepth(nb, 0), subsize(nb, 1);
@@ -1948,6 +2038,17 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   std::vector<float4> gtab(g_info.size() * GT_STRIDE), ptab(p_plane.size() * PT_STRIDE);
   for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
   for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; ptab[p * PT_STRIDE + 2] = p_hq[p]; ptab[p * PT_STRIDE + 3] = p_hs[p]; }
+  D.npair = cons ? m->npair : 0; D.nfl = 0; D.qtab = nullptr;
+  {
+    std::vector<float4> qtab((m->npair ? m->npair : 1) * QT_STRIDE, f4(0, 0, 0, 0));
+    for (int p = 0; p < m->npair; p++) {
+      const double mu = m->pair_friction[p] > 1e-5 ? m->pair_friction[p] : 1e-5;       // mjMINMU
+      qtab[p * QT_STRIDE] = make_float4(ibits(m->pair_geom1[p]), ibits(m->pair_geom2[p]), (float)mu, 0.f);
+      qtab[p * QT_STRIDE + 1] = f4(m->pair_solref[2 * p], m->pair_solref[2 * p + 1], m->pair_solimp[5 * p], m->pair_solimp[5 * p + 1]);
+      qtab[p * QT_STRIDE + 2] = f4(m->pair_solimp[5 * p + 2], m->pair_solimp[5 * p + 3], m->pair_solimp[5 * p + 4], 0);
+    }
+    UP(qtab, qtab);
+  }
   D.hf_nrow = D.hf_ncol = 0; D.hf_data = nullptr;
   if (n_hfield) {
     std::vector<float> hf((size_t)m->hfield_nrow * m->hfield_ncol);
@@ -2057,7 +2158,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   c->ngeom = m->ngeom; c->geom_sensor.assign(m->ngeom ? m->ngeom : 1, -1); c->n_contact_rows = 0; c->d_geom_sensor = nullptr; c->d_pairs = nullptr; c->n_pairs = 0;
   c->geom_is_plane.assign(m->ngeom ? m->ngeom : 1, 0);
   for (int g = 0; g < m->ngeom; g++) c->geom_is_plane[g] = m->geom_type[g] == FMJ_GEOM_PLANE || m->geom_type[g] == FMJ_GEOM_HFIELD;
-  D.cons_rows = nullptr; D.cons_a = nullptr; D.cons_z = nullptr;
+  D.cons_rows = nullptr; D.cons_a = nullptr; D.cons_z = nullptr; D.cons_zf = nullptr;
   if (D.cons && D.maxefc > 0) {   // HBM scratch of envs whose constraint rows outgrow LDS (fmj_step_kernel<.., CONS = true>, "big" path)
     void* p1 = nullptr; void* p2 = nullptr;
     void* p3 = nullptr;
@@ -2071,8 +2172,15 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     }
     c->allocs.push_back(p1); c->allocs.push_back(p2); c->allocs.push_back(p3);
     D.cons_rows = (float*)p1; D.cons_a = (float*)p2; D.cons_z = (float*)p3;
+    if (D.npair > 0) {
+      void* p4 = nullptr;
+      if (hipMalloc(&p4, (size_t)n_envs * D.maxefc * D.rs * sizeof(float)) != hipSuccess) { fmj_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_create: out of device memory for the constraint scratch"); }
+      c->allocs.push_back(p4);
+      D.cons_zf = (float*)p4;
+    }
   }
-  LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs);
+  LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs, D.npair);
+  D.nfl = L.nfl;
   c->lds_bytes = (size_t)L.total * sizeof(float);
   c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
   c->lds_bytes_dual2 = D.dual_ok ? (size_t)(2 * lds2_layout(nb, nv, nq, D.rs, D.dual_t0).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;

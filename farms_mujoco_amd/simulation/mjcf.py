@@ -76,9 +76,6 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                    forcelimited=kwargs.pop('act_vel_forcelimited', False), forcerange=kwargs.pop('act_vel_forcerange', [-1e6, 1e6]))
     assert not kwargs, kwargs
     check_supported_options(simulation_options)
-    if animat_options is not None and getattr(animat_options.morphology, 'self_collisions', None):
-        raise NotImplementedError('morphology.self_collisions (reference mjcf.py:1012-1033: explicit geom-geom contact pairs) '
-                                  'is outside the HIP subset: collision geoms only collide with world-attached planes')
 
     timestep = 1e-3
     gravity = [0.0, 0.0, -9.81]
@@ -187,6 +184,12 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                      friction=(0, 0, 0))
         b.options['max_contacts'] = max(int(b.options['max_contacts']), 32)
 
+    # self-collisions (:1005-1033): one explicit pair per pair of collision shapes of the two links, condim 3, friction 0
+    if animat_options is not None and getattr(animat_options.morphology, 'self_collisions', None):
+        assert use_collisions, 'morphology.self_collisions needs the collision geoms (use_collisions)'
+        for link1, link2 in animat_options.morphology.self_collisions:
+            b.add_contact_pair(link1, link2, friction=0.0, solref=solref if solref is not None else DEFAULT_SOLREF)
+        b.options['max_contacts'] = max(int(b.options['max_contacts']), 32)
     # actuators: position / velocity / motor per joint (:791-866)
     if use_actuators:
         joint_names = (animat_options.control.joints_names() if animat_options is not None
@@ -257,7 +260,9 @@ def setup_model(simulation_options, animat_options, arena_options=None, **kwargs
     plane = hfield is None and arena_options is not None and getattr(arena_options, 'ground_height', None) is not None
     mujoco_kw = dict(getattr(animat_options, 'mujoco', {}) or {})
     return sdf2model(sdf, animat_options=animat_options, simulation_options=simulation_options, hfield=hfield,
-                     fixed_base=mujoco_kw.pop('fixed_base', False), use_collisions=plane or hfield is not None, plane=plane,
+                     fixed_base=mujoco_kw.pop('fixed_base', False),
+                     use_collisions=plane or hfield is not None or bool(getattr(animat_options.morphology, 'self_collisions', None)),
+                     plane=plane,
                      **{k: v for k, v in mujoco_kw.items()
                         if k in ('solref', 'solimp', 'friction') or k.startswith(('act_pos_', 'act_vel_'))}, **kwargs)
 

@@ -553,3 +553,145 @@ def test_flat_heightfield_equals_plane_on_the_gpu(oracle):
         assert int(phys.data.status.abs().sum()) == 0 and int(phys.data.ncon.min()) >= 3
         outs.append(phys.data.qpos.cpu().numpy())
     assert np.abs(outs[0] - outs[1]).max() < 2e-4
+
+
+def test_self_collision_pairs_match_oracle(oracle):
+    """SURVEY 8 f4, explicit self-collision pairs (reference mjcf.py:1012-1033): constraint rows over TWO branches of
+    the tree (J = J(body2) - J(body1)).  A scissors mechanism (two arms on one post) with sphere and with capsule tips:
+    contact record, contact force and accelerations of a single step, then a rollout, against the oracle."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from test_oracle_contacts import _scissors
+    for capsule in (False, True):
+        m, q = _scissors(0.1, capsule=capsule)
+        n = 6
+        rng = np.random.default_rng(3)
+        qpos = np.tile(q, (n, 1)) + rng.uniform(-0.03, 0.03, (n, 2)); qpos[n - 1] = [0.6, -0.6]      # the last env is open: no contact
+        qvel = rng.normal(size=(n, 2))*0.2
+        phys = BatchedPhysics(m, n)
+        q32, v32 = _set(phys, qpos, qvel)
+        phys.step(1)
+        torch.cuda.synchronize()
+        d = phys.data
+        assert int(d.status.abs().sum()) == 0
+        fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+        ncon_ref = np.array([fd['ncon'] for fd in fds])
+        assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref) and ncon_ref[:-1].min() == 1 and ncon_ref[-1] == 0
+        ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+        for e in range(n - 1):
+            got = oracle.contacts_from_hip(d.contact.cpu().numpy()[e, :1])[0]
+            want = fds[e]['contact'][0]
+            assert got[15] == want[15] and got[16] == want[16]
+            assert np.allclose(got[:12], want[:12], atol=2e-6)
+            assert abs(got[12] - want[12]) < 2e-3*abs(want[12]) + 1e-5, (capsule, e, got[12], want[12])
+        assert _relerr(d.qvel.cpu().numpy(), ref['qvel']) < 1e-4 and _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 1e-6
+        phys.step(199)
+        torch.cuda.synchronize()
+        ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=200)
+        assert int(d.status.abs().sum()) == 0
+        assert np.abs(d.qpos.cpu().numpy() - ref['qpos']).max() < 2e-4, capsule
+
+
+def _salamander_self_collisions(spawn_z=0.045):
+    """The walking salamander with explicit pairs between neighbouring limbs and between head and tail, over the plane."""
+    import farms_mujoco_amd.model as mm
+    ref = mm.salamander33(contacts=True, limits=True, spawn_z=spawn_z)
+    b = mm.ModelBuilder('salamander33_sc', timestep=1e-3)
+    m = ref
+    for i in range(1, m.nbody):
+        j = int(m.body_jntadr[i])
+        kw = dict(pos=m.body_pos[i], quat=m.body_quat[i], mass=m.body_mass[i], ipos=m.body_ipos[i], inertia=m.body_inertia[i], iquat=m.body_iquat[i])
+        if m.jnt_type[j] == 0:
+            b.add_body(m.body_names[i], 'world', joint='free', **kw)
+        else:
+            b.add_body(m.body_names[i], m.body_names[m.body_parentid[i]], joint='hinge', jname=m.joint_names[j], axis=m.jnt_axis[j],
+                       damping=m.dof_damping[m.jnt_dofadr[j]], limited=bool(m.jnt_limited[j]), range=m.jnt_range[j], **kw)
+    for g in range(m.ngeom):
+        b.add_geom(m.body_names[m.geom_bodyid[g]], int(m.geom_type[g]), m.geom_size[g], pos=m.geom_pos[g], quat=m.geom_quat[g],
+                   friction=m.geom_friction[g])
+    for a in range(m.nu):
+        if m.actuator_tags[a] == 'position':
+            b.add_position_actuator(m.joint_names[m.actuator_jntid[a]], kp=m.actuator_gain[a])
+    b.options['max_contacts'] = 32
+    for pair in (('leg_front_L_3', 'leg_front_R_3'), ('leg_hind_L_3', 'leg_hind_R_3'), ('body_0', 'body_11'), ('body_2', 'body_10'),
+                 ('leg_front_L_3', 'body_2'), ('leg_hind_R_3', 'body_6'), ('leg_front_R_3', 'body_1'), ('leg_hind_L_3', 'leg_front_L_3')):
+        b.add_contact_pair(*pair)
+    return b.compile()
+
+
+def test_self_collisions_with_ground_contacts_match_oracle(oracle):
+    """Ground contacts and self-collision pairs in the same env: a salamander curled so that its head meets its tail and
+    a foot its trunk, lying on the plane.  Contact lists in the oracle's order (ground first, then pairs), forces and the
+    state after 40 steps; the body-pair contact sensor (reference physics.py:367-374) reads the pair's force with the
+    sign convention of sensors.pyx:163-169."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from farms_mujoco_amd.simulation.physics import get_sensor_maps, get_physics2data_maps, physics2data
+    from farms_mujoco_amd.units import SimulationUnitScaling
+    m = _salamander_self_collisions()
+    assert m.npair == 8
+    n = 8
+    rng = np.random.default_rng(21)
+    plane = int(np.nonzero(m.geom_type == 0)[0][0])
+    spine = [m.jnt_qposadr[m.joint_names.index(f'joint_body_{i}')] for i in range(1, 12)]
+    legj = [m.jnt_qposadr[m.joint_names.index(f'joint_leg_{t}_{s_}_{k}')] for t in ('front', 'hind') for s_ in ('L', 'R') for k in range(4)]
+    poses = []
+    # two leg configurations in which the two front / the two hind feet meet under the trunk (rows over two sibling branches)
+    for legs in ([-1.19, 0.07, -0.84, -0.74, 0.24, -0.09, 1.01, -0.27, 0.42, -0.19, 0.52, -0.12, -0.63, 0.83, 0.69, -0.46],
+                 [-0.25, -0.11, 0.59, -0.16, 1.02, 0.67, 0.77, -0.62, -0.01, -0.32, -0.9, 0.36, 0.78, 0.27, 1.14, -0.7]):
+        q = m.qpos0.copy(); q[2] = 0.05; q[legj] = legs; poses.append(q)
+    # curled up: the head meets the tail (one body's chain contains the other's)
+    for curl in (0.645, 0.65):
+        q = m.qpos0.copy(); q[2] = 0.03; q[spine] = curl; poses.append(q)
+    # random leg poses in which a foot touches the trunk (found with the oracle's collision pass)
+    while len(poses) < n:
+        q = m.qpos0.copy(); q[2] = 0.05; q[spine] = rng.uniform(-0.1, 0.1, 11); q[legj] = rng.uniform(-1.2, 1.2, len(legj))
+        fd = oracle.forward_debug(m, q, np.zeros(m.nv))
+        c = fd['contact'][:fd['ncon']]
+        if ((c[:, 15] != plane) & (c[:, 17] > -0.01)).sum() >= 1 and (c[:, 17] > -0.012).all():
+            poses.append(q)
+    qpos = np.array(poses)
+    qvel = 0.02*rng.normal(size=(n, m.nv))
+    phys = BatchedPhysics(m, n)
+    q32, v32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref)
+    n_pair_contacts = 0
+    kinds = set()
+    for e in range(n):
+        fd = fds[e]
+        got = oracle.contacts_from_hip(d.contact.cpu().numpy()[e, :fd['ncon']])
+        want = fd['contact'][:fd['ncon']]
+        assert np.array_equal(got[:, 15:17], want[:, 15:17])
+        n_pair_contacts += int((want[:, 15] != plane).sum())
+        kinds |= {(int(a_), int(b_)) for a_, b_ in want[want[:, 15] != plane][:, 15:17]}
+        assert np.allclose(got[:, :12], want[:, :12], atol=5e-6)
+        assert np.allclose(got[:, 12], want[:, 12], rtol=3e-2, atol=5e-4), (e, np.abs(got[:, 12] - want[:, 12]).max())
+    assert n_pair_contacts >= n and len(kinds) >= 4                    # every env is in self-contact; feet, trunk, head and tail take part
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+    assert _relerr(d.qvel.cpu().numpy(), ref['qvel']) < 3e-3 and _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 1e-5
+    # body-pair sensors on the current contact list
+    pairs = [('body_0', 'body_11'), ('body_11', 'body_0'), ('body_0', '')]
+    data = AnimatData(m.timestep, 1, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    maps = {'sensors': get_sensor_maps(phys)}
+    get_physics2data_maps(phys, data.sensors, maps['sensors'])
+    physics2data(phys, 0, data, maps, SimulationUnitScaling())
+    torch.cuda.synchronize()
+    rows = data.sensors.contacts.array[0].cpu().numpy().astype(np.float64)
+    want = oracle.contacts2data(oracle.contacts_from_hip(d.contact.cpu().numpy()), d.ncon.cpu().numpy(), maps['sensors']['geompair2data'], len(pairs))
+    assert np.allclose(rows, want, rtol=1e-5, atol=1e-7)
+    touching = np.linalg.norm(rows[:, 0, 6:9], axis=1) > 1e-4
+    assert touching.any() and np.allclose(rows[touching, 1, :9], -rows[touching, 0, :9], rtol=1e-6)
+    phys.step(39)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=40, n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    err = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print('self-collision + ground rollout: qpos abs err per env', err)
+    assert err.max() < 5e-3 and np.median(err) < 1e-3

@@ -236,8 +236,8 @@ def _scissors(theta=0.35, r=0.03, L=0.2, friction=0.0, capsule=False):
     for name, sgn in (('arm_a', +1), ('arm_b', -1)):
         b.add_body(name, 'post', mass=0.2, ipos=(L/2, 0, 0), inertia=(1e-5, 7e-4, 7e-4), joint='hinge', axis=(0, 0, 1), damping=1e-3,
                    qpos0=0.0)
-        if capsule:
-            b.add_geom(name, GEOM_CAPSULE, (r, L/2), pos=(L/2, 0, 0), quat=axisangle2quat([0, 1, 0], np.pi/2))
+        if capsule:                    # the outer half of the arm: the two capsules only meet when the arms close
+            b.add_geom(name, GEOM_CAPSULE, (r, L/4), pos=(0.75*L, 0, 0), quat=axisangle2quat([0, 1, 0], np.pi/2))
         else:
             b.add_geom(name, GEOM_SPHERE, (r,), pos=(L, 0, 0))
     b.add_contact_pair('arm_a', 'arm_b', friction=friction)
@@ -278,8 +278,9 @@ def test_self_collision_capsules_closest_points(oracle):
     fd = oracle.forward_debug(m, q, np.zeros(2))
     assert fd['ncon'] == 1
     ct = fd['contact'][0]
-    # the segments start at the common hinge: closest points are the segment starts (distance 0): full overlap 2 r
-    assert abs(ct[17] + 2*r) < 1e-9 and np.allclose(ct[:3], [0, 0, 0.5], atol=1e-9)
+    # the segments run from L/2 to L along the arms: their closest points are the inner ends, 2 (L/2) sin(theta) apart
+    assert abs(ct[17] - (L*np.sin(0.2) - 2*r)) < 1e-9 and np.allclose(ct[:3], [0.5*L*np.cos(0.2), 0, 0.5], atol=1e-9)
+    assert oracle.forward_debug(m, np.array([0.4, -0.4]), np.zeros(2))['ncon'] == 0
     # parallel capsules side by side
     from farms_mujoco_amd.model import GEOM_CAPSULE, axisangle2quat
     b = ModelBuilder('par', timestep=1e-3, gravity=(0, 0, 0))

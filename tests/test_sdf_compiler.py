@@ -242,3 +242,21 @@ def test_arena_heightmap_compiles_to_heightfield(sdf_path, tmp_path):
     assert m.max_contacts >= 32 and (m.geom_type != GEOM_HFIELD).sum() == 2   # head capsule + trunk sphere collide with it
     c = m.as_c()
     assert c.hfield_nrow == 6 and c.hfield_ncol == 9 and abs(c.hfield_data[3] - want.ravel()[3]) < 1e-15
+
+
+def test_self_collisions_become_contact_pairs(sdf_path):
+    """morphology.self_collisions (reference mjcf.py:1005-1033): every pair of collision shapes of the two links becomes an
+    explicit pair, friction 0, the global solref if one is given."""
+    ao = _options(sdf_path)
+    ao.morphology.self_collisions = [['head', 'trunk']]
+    ao.mujoco = dict(solref=[0.01, 1.0])
+    m = setup_model(SimulationOptions(timestep=1e-3), ao, ArenaOptions(ground_height=0.0))
+    assert m.npair == 1
+    g1, g2 = int(m.pair_geom1[0]), int(m.pair_geom2[0])
+    assert m.body_names[m.geom_bodyid[g1]] == 'head' and m.body_names[m.geom_bodyid[g2]] == 'trunk'
+    assert m.pair_friction[0] == 0.0 and np.allclose(m.pair_solref[0], [0.01, 1.0])
+    c = m.as_c()
+    assert c.npair == 1 and c.pair_geom1[0] == g1 and c.pair_geom2[0] == g2
+    # without an arena the pairs alone switch the collision geoms on
+    m2 = setup_model(SimulationOptions(timestep=1e-3), ao, ArenaOptions())
+    assert m2.npair == 1 and m2.ngeom == 2 and m2.max_contacts >= 32
