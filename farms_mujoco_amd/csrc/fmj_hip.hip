@@ -771,7 +771,9 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 #define STAMP(i)
 #endif
 
-template <bool FUSED, int MAXD, bool CONS>
+// PAIRS: the model has explicit geom pairs (rows over two branches of the tree); a separate instantiation because the
+// fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills.
+template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
   extern __shared__ __align__(16) float lds[];
   const int env = A.env_order ? A.env_order[blockIdx.x] : blockIdx.x;
@@ -1387,7 +1389,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         }
       }
       int ncg = ncon;                               // ground contacts; explicit pairs follow, in pair order (like the oracle)
-      if (M.npair) {
+      if (PAIRS && M.npair) {
         for (int p0 = 0; p0 < M.npair; p0 += 64) {
           const int pr = p0 + lane;
           bool hit = false; v3 pos = mk3(0.f, 0.f, 0.f), nrm = mk3(0.f, 0.f, 1.f); float dist = 0.f, mu = 0.f; int g1 = 0, g2 = 0;
@@ -1455,7 +1457,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       //     Up to LL.na rows everything stays on chip ("small": the rows overlay T/F, V/BUF and CI, dead by now); with
       //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
       const int e_p0 = nlim + 4 * ncg;              // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
-      const bool hasp = M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
+      const bool hasp = PAIRS && M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
       if (nefc <= LL.na && nefc - e_p0 <= LL.nfl) {
         constexpr bool small = true;
         float* const YC = YJ;
@@ -1553,6 +1555,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
   if (dual) return fused ? (void*)fmj_step_dual_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual_kernel<false, FMJ_TU_MAXD>;
+  if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
 }
@@ -1688,7 +1691,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, bool cons, int dual) {
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1702,10 +1705,10 @@ static step_kernel_t tu_kernel(int rs, bool fused, bool cons, int dual) {
   }
   return (step_kernel_t)k;
 }
-static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons != 0, 0); }
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons ? (c->dm.npair > 0 ? 2 : 1) : 0, 0); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc / fmj_dual.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, false, c->dual_gen == 2 && c->dual_wps == 3 ? 3 : c->dual_gen);
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_gen == 2 && c->dual_wps == 3 ? 3 : c->dual_gen);
     hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
