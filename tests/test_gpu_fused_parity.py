@@ -313,3 +313,33 @@ def test_full_size_config2_properties(oracle, N):
     assert _relerr(links[:, :8], ref['links']) < 2e-4
     # the animals did swim: forward displacement of the root along -x/+x beyond a body width
     assert np.abs(q[:, 0] - qpos[:, 0]).mean() > 0.02
+
+
+@pytest.mark.parametrize('env', [dict(FMJ_DUAL='1'), dict(FMJ_WPS='3'), dict(FMJ_WPS='4'), dict(FMJ_DUAL='0')])
+def test_every_step_kernel_build_matches_oracle(oracle, env, monkeypatch):
+    """The kernel a context uses is picked at fmj_create (batch size, model, FMJ_* switches): round 1's two-env kernel,
+    round 2's in its 168- and 128-register builds, and the one-env kernel all reproduce the oracle on the same fused
+    workload (odd batch: the last wave of the two-env kernels has an idle half)."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    n, T = 7, 120
+    sim, m, psi = _make_sim(n, T, buffer_size=40, water_kwargs=dict(height=-0.11, velocity=[0.03, 0.0, -0.01]))
+    info = sim.physics.kernel_info()
+    assert info['threads_per_env'] == (64 if env.get('FMJ_DUAL') == '0' else 32)
+    st = _oracle_initial_state(oracle, sim, m)
+    swim, water = _swim_water(sim)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    c = sim.task._controller
+    wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
+                env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency)
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=40, controller=1, wave=wave, n_threads=8)
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    sens = sim.task.data.sensors
+    errs = dict(qpos=_relerr(d.qpos.cpu().numpy(), ref['qpos']), links=_relerr(sens.links.array.cpu().numpy(), ref['links']),
+                joints=_relerr(sens.joints.array.cpu().numpy(), ref['joints']), xfrc=_relerr(sens.xfrc.array.cpu().numpy(), ref['xfrc']),
+                sensordata=_relerr(d.sensordata.cpu().numpy(), ref['sensordata']))
+    print(env, errs)
+    assert errs['qpos'] < 1e-4 and errs['links'] < 1e-4 and errs['joints'] < 1e-3 and errs['xfrc'] < 1e-3 and errs['sensordata'] < 2e-3, errs
