@@ -124,6 +124,43 @@ def cpu_baseline(m, sim, target_seconds=15.0):
                        f'(not MuJoCo), {cores} pthreads, {dt:.2f} s')
 
 
+def other_workloads(n_envs, chunk, device):
+    """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS) and configs[4] (eel + centipede buckets) on
+    this GPU: env-steps/s over 500 timed steps after a warm-up (walking: 1000 steps, so that the animals stand and walk)."""
+    import torch
+    res = {}
+    for name, warm, steps in (('walk', 1000, 500), ('mixed', 300, 500)):
+        if name == 'mixed':
+            sims = [build_sim(n_envs//2, 1 << 30, chunk, 0, device, morphology='eel')[0],
+                    build_sim(n_envs - n_envs//2, 1 << 30, chunk, n_envs//2, device, morphology='centipede')[0]]
+        else:
+            sims = [build_sim(n_envs, 1 << 30, chunk, 0, device, workload='walk')[0]]
+        for _ in range(warm//chunk):
+            for s_ in sims:
+                s_.step_fused(chunk)
+        torch.cuda.synchronize()
+        evs = []
+        t0 = time.perf_counter()
+        for _ in range(steps//chunk):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for s_ in sims:
+                s_.step_fused(chunk)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        for s_ in sims:
+            s_.physics.check_invalid_state()
+        ms = np.array([a.elapsed_time(b) for a, b in evs])
+        res[name] = {'value': n_envs*(steps//chunk)*chunk/dt, 'unit': 'env-steps/s', 'warmup': warm, 'steps': (steps//chunk)*chunk,
+                     'launch_ms': {'min': float(ms.min()), 'median': float(np.median(ms)), 'max': float(ms.max())},
+                     'config': 'BASELINE configs[3]: salamander-33 walking on a plane' if name == 'walk' else
+                               'BASELINE configs[4]: half eels, half centipedes, one bucket per morphology'}
+        del sims
+    return res
+
+
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (one per GPU, through
     torch.distributed.run) before this process makes any GPU call, stream their output through, exit with their code."""
@@ -148,6 +185,7 @@ def main():
     ap.add_argument('--min-seconds', type=float, default=0.25,
                     help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-extras', action='store_true', help='skip the short walk / mixed measurements appended to the swim line')
     ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed'],
                     help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede')
     ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --same-device rehearses the N>1 path on a 1-GPU box")
@@ -280,6 +318,12 @@ def main():
                          'note': 'the step is bound by dependent-chain latency and VALU issue of the tree recursions, not by HBM '
                                  '(binding: share of SQ_WAVE_CYCLES by SQ counter, profiles/): HBM is the nominal bound (SURVEY 8d)'},
         }
+        if world == 1 and not args.no_extras and args.workload == 'swim':
+            # the other BASELINE configurations, briefly, so that the driver's record carries them too (never the headline)
+            try:
+                out['other_workloads'] = other_workloads(n_envs, chunk, device)
+            except Exception as e:
+                out['other_workloads'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:
                 out['cpu_baseline'] = cpu_baseline(m, sim)
