@@ -9,8 +9,10 @@ names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L'
          'A', 'warm', 'PGS', 'qfrc_c', '-', '-', '-']
 workload = os.environ.get('FMJ_WORKLOAD', 'swim')
 for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
-    sim, m, _ = bench.build_sim(n, 300, 100, 0, 'cuda:0', workload)
-    sim.step_fused(100); sim.step_fused(100); torch.cuda.synchronize()
+    sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
+    for _ in range(int(os.environ.get('FMJ_STAMP_WARM', '100')) // 100 + 1):
+        sim.step_fused(100)
+    torch.cuda.synchronize()
     st = sim.physics.data.qacc[0, :24].cpu().numpy()/100.0
     tot = st.sum()
     print(f'n_envs={n}: cycles/step {tot:.0f}')
