@@ -110,17 +110,34 @@ struct DevModel {
 #define PT_STRIDE 4    // per ground geom: plane (n, offset) or heightfield position; prm (friction, heightfield flag, geom id); heightfield quat; heightfield rx, ry, size z
 __device__ __forceinline__ unsigned __float_as_uint_(float f) { return (unsigned)__float_as_int(f); }
 __device__ __forceinline__ int4 as_int4(float4 v) { return make_int4(__float_as_int(v.x), __float_as_int(v.y), __float_as_int(v.z), __float_as_int(v.w)); }
-#define BTAB(b, k) (M.btab[(unsigned)(b) * BT_STRIDE + (k)])
+// Global-memory accesses are typed (address space 1) at the access: a pointer that reaches a kernel through the kernarg
+// segment (scalar loads where it is used, see the step kernels) is a generic pointer to the compiler, and a generic
+// access is a flat instruction.
+#define AS1 __attribute__((address_space(1)))
+#define AS4 __attribute__((address_space(4)))
+template <class T> __device__ __forceinline__ const T AS1* gptr(const T* p) { return (const T AS1*)p; }
+template <class T> __device__ __forceinline__ T AS1* gptr(T* p) { return (T AS1*)p; }
+// float4 / float2 are classes in HIP: global accesses go through the native vector types
+typedef float vf4_t __attribute__((ext_vector_type(4)));
+typedef float vf2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float4 ldg4(const float4* p, unsigned i) { const vf4_t v = ((const vf4_t AS1*)p)[i]; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ float4 ldg4f(const float* p) { const vf4_t v = *(const vf4_t AS1*)p; return make_float4(v.x, v.y, v.z, v.w); }
+__device__ __forceinline__ void stg4(float AS1* p, float a, float b, float c, float d) { *(vf4_t AS1*)p = vf4_t{a, b, c, d}; }
+__device__ __forceinline__ void stg2(float AS1* p, float a, float b) { *(vf2_t AS1*)p = vf2_t{a, b}; }
+// generic -> global -> generic: the address-space inference then types every access made through the result as global
+template <class T> __device__ __forceinline__ T* glob(T* p) { return (T*)(T AS1*)p; }
+__device__ __forceinline__ float2 ldg2f(const float* p) { const vf2_t v = *(const vf2_t AS1*)p; return make_float2(v.x, v.y); }
+#define BTAB(b, k) ldg4(M.btab, (unsigned)(b) * BT_STRIDE + (k))
 #define BTABI(b, k) as_int4(BTAB(b, k))
-#define DTAB(d, k) (M.dtab[(unsigned)(d) * DT_STRIDE + (k)])
+#define DTAB(d, k) ldg4(M.dtab, (unsigned)(d) * DT_STRIDE + (k))
 #define DTABI(d, k) as_int4(DTAB(d, k))
-#define ATAB(a, k) (M.atab[(unsigned)(a) * AT_STRIDE + (k)])
-#define MTAB(e) (M.mtab[(unsigned)(e)])
-#define STAB(i, k) (M.stab[(unsigned)(i) * ST_STRIDE + (k)])
-#define GTAB(g, k) (M.gtab[(unsigned)(g) * GT_STRIDE + (k)])
+#define ATAB(a, k) ldg4(M.atab, (unsigned)(a) * AT_STRIDE + (k))
+#define MTAB(e) ldg4(M.mtab, (unsigned)(e))
+#define STAB(i, k) ldg4(M.stab, (unsigned)(i) * ST_STRIDE + (k))
+#define GTAB(g, k) ldg4(M.gtab, (unsigned)(g) * GT_STRIDE + (k))
 #define GTABI(g, k) as_int4(GTAB(g, k))
-#define PTAB(p, k) (M.ptab[(unsigned)(p) * PT_STRIDE + (k)])
-#define QTAB(p, k) (M.qtab[(unsigned)(p) * QT_STRIDE + (k)])
+#define PTAB(p, k) ldg4(M.ptab, (unsigned)(p) * PT_STRIDE + (k))
+#define QTAB(p, k) ldg4(M.qtab, (unsigned)(p) * QT_STRIDE + (k))
 
 struct StepArgs {
   float* qpos; float* qvel; const float* ctrl; const float* qpos_spring; const float* xfrc_applied;
@@ -139,6 +156,9 @@ struct StepArgs {
   const int* env_order;       // one-env kernel: env of workgroup b (NULL: b); heavier envs first shortens a launch's tail
   float* dbg_H; float* dbg_qfrc;   // fmj_forward_debug: rows of H = M + diag(armature + h damping) [n_envs][nv][rs], qfrc_smooth [n_envs][nv]
 };
+
+static_assert(alignof(DevModel) == 8 && alignof(StepArgs) == 8, "kernarg layout of (DevModel, StepArgs)");
+#define FMJ_KARG_A_OFF ((sizeof(DevModel) + 7) & ~(size_t)7)
 
 struct fmj_ctx {
   int device, n_envs;
@@ -347,8 +367,9 @@ __device__ __forceinline__ bool drag_link(v3 com_pos, fq urdf2global, fq com2glo
 // Same law for the fused loop, where the link's CoM orientation IS its body orientation (reference
 // physics.py:455-466 fills both from xquat), so com2urdf is the identity (drag.pyx:46-47,261-262 become no-ops)
 // and every quaternion sandwich q v q* collapses to one rotation matrix: ~80 VALU instead of ~400.
+template <class AT>
 __device__ __forceinline__ bool drag_link_same_frames(v3 com_pos, q4 q_wxyz, v3 lin_w, v3 ang_w, float4 c0, float4 c1,
-                                                      float density, const StepArgs& A, v3* force_link, v3* force_w, v3* torque_link, v3* torque_w) {
+                                                      float density, AT& A, v3* force_link, v3* force_w, v3* torque_link, v3* torque_w) {
   if (com_pos.z > A.surface) return false;                     // drag.pyx:192-194
   const m33 R = q2m(q_wxyz);                                   // link -> world
   // world -> link = R^T  (drag.pyx:50-63, 235-244)
@@ -562,7 +583,7 @@ __device__ __forceinline__ float ldl_pull_sweep(const float* HR, float x, int dl
   for (int g = 0; g < MAXD / 4; g++) row[g] = *(const float4*)(HR + dli * RS + 4 * g);
 #pragma unroll
   for (int g = 0; g < MAXD / 4; g++) {
-    const uint32_t ab = ancl[(unsigned)dli * (MAXD / 4) + g];
+    const uint32_t ab = gptr(ancl)[(unsigned)dli * (MAXD / 4) + g];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const int lvl = 4 * g + k;
@@ -657,7 +678,8 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
 // size z): the plane of the grid triangle under p (cells split along the diagonal (c, r) - (c + 1, r + 1)); nothing outside
 // the grid.  PTAB(pl, 1).y != 0 marks a heightfield, PTAB(pl, 0) then holds its position, (pl, 2) its quaternion, (pl, 3)
 // rx, ry, size z.
-__device__ __forceinline__ float ground_dist(const DevModel& M, int pl, float4 pn, float4 pp, v3 p, v3* n) {
+template <class MT>
+__device__ __forceinline__ float ground_dist(MT& M, int pl, float4 pn, float4 pp, v3 p, v3* n) {
   if (pp.y == 0.f) { *n = mk3(pn.x, pn.y, pn.z); return dot3(p, *n) - pn.w; }
   const float4 hq = PTAB(pl, 2), hs = PTAB(pl, 3);
   const q4 q = {hq.x, hq.y, hq.z, hq.w}, qc = {hq.x, -hq.y, -hq.z, -hq.w};
@@ -669,7 +691,7 @@ __device__ __forceinline__ float ground_dist(const DevModel& M, int pl, float4 p
   if (!(gx >= 0.f && gx <= (float)(nc - 1) && gy >= 0.f && gy <= (float)(nr - 1))) return 1e30f;
   const int c = min((int)gx, nc - 2), r = min((int)gy, nr - 2);
   const float fx = gx - (float)c, fy = gy - (float)r;
-  const float* D = M.hf_data + (size_t)r * nc + c;
+  const float AS1* D = gptr(M.hf_data) + (size_t)r * nc + c;
   const float z00 = D[0] * hs.z, z10 = D[1] * hs.z, z01 = D[nc] * hs.z, z11 = D[nc + 1] * hs.z;
   float zs, gxs, gys;                                          // surface height under p and its slopes per cell
   if (fx >= fy) { gxs = z10 - z00; gys = z11 - z10; } else { gxs = z11 - z01; gys = z01 - z00; }
@@ -684,9 +706,12 @@ __device__ __forceinline__ float ground_dist(const DevModel& M, int pl, float4 p
 // Contact records: pos(3) frame(9) force(3: normal,t1,t2) int32 geom1 << 16 | geom2.  The four keys of
 // sensors.pyx:163-169 in the reference's order: (g1,g2) -1, (g2,g1) +1, (g1,-1) -1, (g2,-1) +1; a key that maps to
 // `row` adds the contact once (a contact can hit one row through several keys, as in the reference).
-__device__ __forceinline__ void contact_row(const float* C, int nc, int row, const int* geom_sensor, int n_pairs, const int* pairs,
-                                            float inv_newtons, float inv_meters, float* out) {
+__device__ __forceinline__ void contact_row(const float* C, int nc, int row, const int* geom_sensor_, int n_pairs, const int* pairs_,
+                                            float inv_newtons, float inv_meters, float* out_) {
   float acc[12]; float norm_sum = 0.f;
+  const int AS1* const geom_sensor = gptr(geom_sensor_);
+  const int AS1* const pairs = gptr(pairs_);
+  float AS1* const out = gptr(out_);
 #pragma unroll
   for (int k = 0; k < 12; k++) acc[k] = 0.f;
   for (int c = 0; c < nc; c++) {
@@ -726,7 +751,8 @@ __device__ __forceinline__ void contact_row(const float* C, int nc, int row, con
 // Emits, for iteration `it`, what ExperimentTask.before_step does with the link data of the last
 // forward pass (reference task.py:168-186): the links row (physics.py:449-466,435-446), the drag of
 // every swimming link (drag.pyx:389-411 -> xfrc row) and the world-frame xfrc_applied of this body.
-__device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const StepArgs& A, int env, int it, bool isb, bool frozen,
+template <class MT, class AT>
+__device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int it, bool isb, bool frozen,
                                                     int link_row, int swim_slot, v3 xpos, q4 xquat, v3 xipos, v3 linvel,
                                                     v3 angvel, float* xf) {
   const int index = it % A.buffer_size;
@@ -734,12 +760,12 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
   const v3 r_lin = scl3(linvel, A.inv_velocity), r_ang = scl3(angvel, A.inv_angvel);
   const fq r_q = {xquat.x, xquat.y, xquat.z, xquat.w};   // wxyz -> xyzw (physics.py:458)
   if (A.do_readout && isb && !frozen && link_row >= 0) {
-    float* row = A.links + ((size_t)index * A.row_stride_links + (size_t)env * M.n_links * FMJ_LINK_SIZE) + link_row * FMJ_LINK_SIZE;
-    *(float4*)(row + 0) = make_float4(r_com.x, r_com.y, r_com.z, r_q.x);
-    *(float4*)(row + 4) = make_float4(r_q.y, r_q.z, r_q.w, r_urdf.x);
-    *(float4*)(row + 8) = make_float4(r_urdf.y, r_urdf.z, r_q.x, r_q.y);
-    *(float4*)(row + 12) = make_float4(r_q.z, r_q.w, r_lin.x, r_lin.y);
-    *(float4*)(row + 16) = make_float4(r_lin.z, r_ang.x, r_ang.y, r_ang.z);
+    float AS1* row = gptr(A.links) + ((size_t)index * A.row_stride_links + (size_t)env * M.n_links * FMJ_LINK_SIZE) + link_row * FMJ_LINK_SIZE;
+    stg4(row + 0, r_com.x, r_com.y, r_com.z, r_q.x);
+    stg4(row + 4, r_q.y, r_q.z, r_q.w, r_urdf.x);
+    stg4(row + 8, r_urdf.y, r_urdf.z, r_q.x, r_q.y);
+    stg4(row + 12, r_q.z, r_q.w, r_lin.x, r_lin.y);
+    stg4(row + 16, r_lin.z, r_ang.x, r_ang.y, r_ang.z);
   }
   if (A.do_drag) {
 #pragma unroll
@@ -749,10 +775,10 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
       v3 fo, to, fw, tw;
       if (drag_link_same_frames(r_com, xquat, r_lin, r_ang, s0, s1, s2.x, A, &fo, &fw, &to, &tw)) {
         if (!frozen) {
-          float* xr = A.xfrc + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
-          *(float2*)(xr + 0) = make_float2(fo.x, fo.y);
-          *(float2*)(xr + 2) = make_float2(fo.z, to.x);
-          *(float2*)(xr + 4) = make_float2(to.y, to.z);
+          float AS1* xr = gptr(A.xfrc) + ((size_t)index * A.row_stride_xfrc + (size_t)env * M.n_xfrc * FMJ_XFRC_SIZE) + __float_as_int(s2.z) * FMJ_XFRC_SIZE;
+          stg2(xr + 0, fo.x, fo.y);
+          stg2(xr + 2, fo.z, to.x);
+          stg2(xr + 4, to.y, to.z);
         }
         xf[0] = fw.x * A.newtons; xf[1] = fw.y * A.newtons; xf[2] = fw.z * A.newtons;
         xf[3] = tw.x * A.torques; xf[4] = tw.y * A.torques; xf[5] = tw.z * A.torques;
@@ -774,9 +800,16 @@ __device__ __forceinline__ void emit_links_and_drag(const DevModel& M, const Ste
 // PAIRS: the model has explicit geom pairs (rows over two branches of the tree); a separate instantiation because the
 // fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills.
 template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false>
-__global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M, const StepArgs A) {
+__global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
-  const int env = A.env_order ? A.env_order[blockIdx.x] : blockIdx.x;
+  // the two arguments are read where they are used, through the kernarg segment (scalar loads), instead of being held
+  // in SGPRs - and spilled - for the whole launch (see fmj_dual2.inc); the pointers are laundered once per step
+  const char AS4* const karg = (const char AS4*)__builtin_amdgcn_kernarg_segment_ptr();
+  const DevModel AS4* Mp = (const DevModel AS4*)karg;
+  const StepArgs AS4* Ap = (const StepArgs AS4*)(karg + FMJ_KARG_A_OFF);
+#define M (*Mp)
+#define A (*Ap)
+  const int env = A.env_order ? gptr(A.env_order)[blockIdx.x] : blockIdx.x;
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
@@ -815,29 +848,29 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     for (int i = lane; i < nw; i += 64) jw[i] = ((const uint32_t*)M.b_anc)[i];
   }
   {
-    const float* gq = A.qpos + (size_t)env * nq;
-    const float* gv = A.qvel + (size_t)env * nv;
+    const float* gq = glob(A.qpos) + (size_t)env * nq;
+    const float* gv = glob(A.qvel) + (size_t)env * nv;
     for (int i = lane; i < nq; i += 64) { const float v = gq[i]; QP[i] = v; if (!(fabsf(v) <= 1e10f)) warn |= FMJ_WARN_BADQPOS; }   // mj_checkPos
     for (int i = lane; i < nv; i += 64) { const float v = gv[i]; QV[i] = v; if (!(fabsf(v) <= 1e10f)) warn |= FMJ_WARN_BADQVEL; }   // mj_checkVel
     if (lane < 8) VT[lane] = 0.f;
-    if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = A.qacc_warmstart[(size_t)env * nv + i];
+    if (CONS) for (int i = lane; i < nv; i += 64) QW[i] = gptr(A.qacc_warmstart)[(size_t)env * nv + i];
     if (CONS) for (int i = lane; i < (nv * nv + 3) / 4; i += 64) ((uint32_t*)LC)[i] = ((const uint32_t*)M.lcad)[i];
   }
   int cy_ncon = 0;                                  // contacts of the last forward pass (records incl. forces stay in CT)
   if (CONS && FUSED && A.contacts_rows) {
-    cy_ncon = A.ncon[env];
-    for (int i = lane; i < cy_ncon * 16; i += 64) CT[i] = A.contact[(size_t)env * M.max_contacts * 16 + i];
+    cy_ncon = gptr(A.ncon)[env];
+    for (int i = lane; i < cy_ncon * 16; i += 64) CT[i] = gptr(A.contact)[(size_t)env * M.max_contacts * 16 + i];
   }
   float cy_limfrc = 0.f;                            // carried joint-limit force of this dof's joint (physics.py:484-487)
-  if (CONS && FUSED && isd) { const int4 da0 = DTABI(dl, 2); if (DTAB(dl, 1).w != 0.f) cy_limfrc = A.sensordata[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
+  if (CONS && FUSED && isd) { const int4 da0 = DTABI(dl, 2); if (DTAB(dl, 1).w != 0.f) cy_limfrc = gptr(A.sensordata)[(size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * da0.z + 2] * A.inv_torques; }
   float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
   float cy_actsum = 0.f;                            // carried motor torque (physics.py:510-524)
   if (FUSED) {
     if (lane < nb) {
-      const float* p = A.xpos + (size_t)env * nb * 3 + lane * 3;
-      const float4 q = *(const float4*)(A.xquat + (size_t)env * nb * 4 + lane * 4);
-      const float* ip = A.xipos + (size_t)env * nb * 3 + lane * 3;
-      const float* sd = A.sensordata + (size_t)env * M.nsensordata + 6 * (isb ? lane - 1 : 0);
+      const float* p = glob(A.xpos) + (size_t)env * nb * 3 + lane * 3;
+      const float4 q = *(const float4*)(glob(A.xquat) + (size_t)env * nb * 4 + lane * 4);
+      const float* ip = glob(A.xipos) + (size_t)env * nb * 3 + lane * 3;
+      const float* sd = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (isb ? lane - 1 : 0);
       *(float4*)(CY + lane * 16) = make_float4(p[0], p[1], p[2], q.x);
       *(float4*)(CY + lane * 16 + 4) = make_float4(q.y, q.z, q.w, ip[0]);
       *(float4*)(CY + lane * 16 + 8) = make_float4(ip[1], ip[2], sd[0], sd[1]);
@@ -846,19 +879,19 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const float4 dp = DTAB(dl, 1);
     if (isd && dp.w != 0.f) {
       const int4 da = DTABI(dl, 2);
-      const float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
+      const float* sa = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;
 #pragma unroll
       for (int a = 0; a < 4; a++) if (a < da.y) cy_actsum += sa[__float_as_int(ATAB(da.x + a, 2).x)] * A.inv_torques;
     }
   }
   if (!(FUSED && A.do_drag) && A.xfrc_applied && isb) {
-    const float* x = A.xfrc_applied + (size_t)env * nb * 6 + bl * 6;
+    const float* x = glob(A.xfrc_applied) + (size_t)env * nb * 6 + bl * 6;
 #pragma unroll
     for (int k = 0; k < 6; k++) xf[k] = x[k];
   }
   // An env with a bad-state bit is frozen (include/fmj.h): it is not integrated and writes no rows, from the step that
   // finds the bad value on and in later launches until the caller clears its status word.
-  bool frozen = (A.status[env] & FMJ_WARN_FREEZE) != 0 || __any((warn & FMJ_WARN_FREEZE) != 0);
+  bool frozen = (gptr(A.status)[env] & FMJ_WARN_FREEZE) != 0 || __any((warn & FMJ_WARN_FREEZE) != 0);
   int steps_done = 0;
   WSYNC();
 #ifdef FMJ_STAMPS
@@ -872,6 +905,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #pragma unroll 1
   for (int step = 0; step < A.n_steps; step++) {
     if (frozen) break;
+    asm volatile("" : "+s"(Mp), "+s"(Ap));       // arguments are re-read from the kernarg segment in every step
     // per-lane LDS/global addresses are recomputed every step instead of being hoisted and spilled
     const int lane = opaque(lane_outer);
     const int it = A.iteration0 + step;
@@ -891,8 +925,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list
       const int index = it % A.buffer_size;
       for (int row = lane; row < A.n_contact_rows; row += 64)
-        contact_row(CT, cy_ncon, row, A.geom_sensor, A.n_pairs, A.pairs, A.inv_newtons, A.inv_meters,
-                    A.contacts_rows + ((size_t)index * A.row_stride_contacts + ((size_t)env * A.n_contact_rows + row) * FMJ_CONTACT_SIZE));
+        contact_row(CT, cy_ncon, row, glob(A.geom_sensor), A.n_pairs, glob(A.pairs), A.inv_newtons, A.inv_meters,
+                    glob(A.contacts_rows) + ((size_t)index * A.row_stride_contacts + ((size_t)env * A.n_contact_rows + row) * FMJ_CONTACT_SIZE));
       WSYNC();
     }
     // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
@@ -901,7 +935,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       const float4 dp = DTAB(dlo, 1);
       if (isd && dp.w != 0.f && di.w >= 0) {
         const int index = it % A.buffer_size;
-        float* row = A.joints + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
+        float* row = glob(A.joints) + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
         row[FMJ_JOINT_POSITION] = QP[__float_as_int(dp.z)];
         row[FMJ_JOINT_VELOCITY] = QV[lane] * A.inv_angvel;
         row[FMJ_JOINT_TORQUE] = cy_actsum;
@@ -1072,11 +1106,11 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         *(float4*)(CY + lane * 16 + 12) = make_float4(linvel.z, cv.r.x, cv.r.y, cv.r.z);
       }
       if (last && lane < nb) {
-        float* p = A.xpos + (size_t)env * nb * 3 + lane * 3; p[0] = xp.x; p[1] = xp.y; p[2] = xp.z;
-        *(float4*)(A.xquat + (size_t)env * nb * 4 + lane * 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
-        float* ip = A.xipos + (size_t)env * nb * 3 + lane * 3; ip[0] = xi.x; ip[1] = xi.y; ip[2] = xi.z;
+        float* p = glob(A.xpos) + (size_t)env * nb * 3 + lane * 3; p[0] = xp.x; p[1] = xp.y; p[2] = xp.z;
+        *(float4*)(glob(A.xquat) + (size_t)env * nb * 4 + lane * 4) = make_float4(xq.w, xq.x, xq.y, xq.z);
+        float* ip = glob(A.xipos) + (size_t)env * nb * 3 + lane * 3; ip[0] = xi.x; ip[1] = xi.y; ip[2] = xi.z;
         if (isb) {
-          float* sp = A.sensordata + (size_t)env * M.nsensordata + 6 * (lane - 1);
+          float* sp = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (lane - 1);
           *(float2*)(sp) = make_float2(linvel.x, linvel.y);
           *(float2*)(sp + 2) = make_float2(linvel.z, cv.r.x);
           *(float2*)(sp + 4) = make_float2(cv.r.y, cv.r.z);
@@ -1152,7 +1186,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         const float qj = QP[d_qadr];
         if (M.any_stiffness) {
           const float kst = BTAB(body, 6).w;
-          if (kst != 0.f) qfrc -= kst * (qj - A.qpos_spring[(size_t)env * nq + d_qadr]);
+          if (kst != 0.f) qfrc -= kst * (qj - gptr(A.qpos_spring)[(size_t)env * nq + d_qadr]);
         }
         float asum = 0.f;
         float cbase = 0.f;
@@ -1160,7 +1194,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
           // phase in cycles kept in fp64 so long runs keep the argument exact (task.py:290: time = iteration*timestep)
           double cyc = (double)A.w_freq * ((double)it * (double)M.h);
           cyc -= floor(cyc);
-          cbase = 6.283185307179586f * (float)cyc + A.w_env[env];
+          cbase = 6.283185307179586f * (float)cyc + gptr(A.w_env)[env];
         }
 #pragma unroll
         for (int a = 0; a < 4; a++) {                 // mj_fwdActuation, joint transmission
@@ -1168,8 +1202,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
             const int ai = d_act.x + a, src = __float_as_int(ATAB(ai, 2).x);
             const float4 p = ATAB(ai, 0), lim = ATAB(ai, 1);
             float c;
-            if (FUSED && A.controller == 1) { const float amp = A.w_amp[src]; c = amp != 0.f ? amp * sinf(cbase - A.w_lag[src]) : 0.f; }
-            else c = A.ctrl ? A.ctrl[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
+            if (FUSED && A.controller == 1) { const float amp = gptr(A.w_amp)[src]; c = amp != 0.f ? amp * sinf(cbase - gptr(A.w_lag)[src]) : 0.f; }
+            else c = A.ctrl ? gptr(A.ctrl)[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
             c = fminf(fmaxf(c, lim.x), lim.y);
             float f = p.x * c + p.y + p.z * qj + p.w * qd;
             f = fminf(fmaxf(f, lim.z), lim.w);
@@ -1184,12 +1218,12 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #pragma unroll
           for (int a = 0; a < 4; a++) if (a < d_act.y) {
             const int src = __float_as_int(ATAB(d_act.x + a, 2).x);
-            const float amp = A.w_amp[src];
-            A.ctrl_out[(size_t)env * nu + src] = amp != 0.f ? amp * sinf(cbase - A.w_lag[src]) : 0.f;
+            const float amp = gptr(A.w_amp)[src];
+            gptr(A.ctrl_out)[(size_t)env * nu + src] = amp != 0.f ? amp * sinf(cbase - gptr(A.w_lag)[src]) : 0.f;
           }
         }
         if (last) {
-          float* sa = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;   // actuatorfrc
+          float* sa = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * M.njs;   // actuatorfrc
           if (0 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 0, 2).x)] = af0;
           if (1 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 1, 2).x)] = af1;
           if (2 < d_act.y) sa[__float_as_int(ATAB(d_act.x + 2, 2).x)] = af2;
@@ -1241,8 +1275,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     WSYNC();
     STAMP(8);   // M
     if (!FUSED && A.dbg_H) {      // fmj_forward_debug: the assembled rows and the right-hand side, before any factorisation
-      for (int i = lane; i < nv * RS; i += 64) A.dbg_H[(size_t)env * nv * RS + i] = HR[i];
-      if (isd) A.dbg_qfrc[(size_t)env * nv + lane] = qfrc;
+      for (int i = lane; i < nv * RS; i += 64) gptr(A.dbg_H)[(size_t)env * nv * RS + i] = HR[i];
+      if (isd) gptr(A.dbg_qfrc)[(size_t)env * nv + lane] = qfrc;
     }
     // ---- constraints (CONS instantiation only): qfrc_constraint from limits + plane contacts via PGS
     float qfrc_c = 0.f;
@@ -1466,9 +1500,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #include "fmj_cons_rows.inc"
       } else {
         constexpr bool small = false;
-        float* const YC = M.cons_z + (size_t)env * M.maxefc * RS;
-        float* const EP = M.cons_rows + (size_t)env * M.maxefc * 8;
-        float* const YF = M.cons_zf ? M.cons_zf + (size_t)env * M.maxefc * RS : nullptr;
+        float* const YC = glob(M.cons_z) + (size_t)env * M.maxefc * RS;
+        float* const EP = glob(M.cons_rows) + (size_t)env * M.maxefc * 8;
+        float* const YF = M.cons_zf ? glob(M.cons_zf) + (size_t)env * M.maxefc * RS : nullptr;
 #include "fmj_cons_rows.inc"
       }
     }
@@ -1497,7 +1531,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         const float pre_q = QP[d_qadr];
         QP[d_qadr] = pre_q + hstep * nvel;
         if (last) {
-          float* s = A.sensordata + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z;   // jointpos, jointvel, jointlimitfrc
+          float* s = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (nb - 1) + 3 * d_act.z;   // jointpos, jointvel, jointlimitfrc
           s[0] = pre_q; s[1] = pre_qd; if (!CONS) s[2] = 0.f;
         }
       }
@@ -1519,28 +1553,30 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   }
 
   // ---- store state ---------------------------------------------------------------------------------------
-  float* oq = A.qpos + (size_t)env * nq;
-  float* ov = A.qvel + (size_t)env * nv;
+  float* oq = glob(A.qpos) + (size_t)env * nq;
+  float* ov = glob(A.qvel) + (size_t)env * nv;
   for (int i = lane; i < nq; i += 64) oq[i] = QP[i];
   for (int i = lane; i < nv; i += 64) ov[i] = QV[i];
-  if (A.qacc && steps_done > 0) for (int i = lane; i < nv; i += 64) A.qacc[(size_t)env * nv + i] = XV[i];
+  if (A.qacc && steps_done > 0) for (int i = lane; i < nv; i += 64) gptr(A.qacc)[(size_t)env * nv + i] = XV[i];
   // mj_step saves qacc as the next warm start when it advances the state; mj_forward alone does not
-  if (CONS && !frozen && A.integrate) for (int i = lane; i < nv; i += 64) A.qacc_warmstart[(size_t)env * nv + i] = QW[i];
+  if (CONS && !frozen && A.integrate) for (int i = lane; i < nv; i += 64) gptr(A.qacc_warmstart)[(size_t)env * nv + i] = QW[i];
 #ifdef FMJ_STAMPS
   if (env == 0 && lane == 0 && A.qacc) {
 #pragma unroll
-    for (int i = 0; i < NSTAMP; i++) A.qacc[i] = stamp_acc[i];
+    for (int i = 0; i < NSTAMP; i++) gptr(A.qacc)[i] = stamp_acc[i];
   }
 #endif
-  if (A.time && lane == 0 && A.integrate) A.time[env] += M.h * steps_done;
+  if (A.time && lane == 0 && A.integrate) gptr(A.time)[env] += M.h * steps_done;
   if (__ballot(warn != 0)) {
     int w = warn;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) w |= __shfl_xor(w, o, 64);
-    if (lane == 0) A.status[env] |= w;
+    if (lane == 0) gptr(A.status)[env] |= w;
   }
 }
 
+#undef M
+#undef A
 #include "fmj_dual.inc"
 #include "fmj_dual2.inc"
 
