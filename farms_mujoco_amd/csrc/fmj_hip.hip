@@ -572,6 +572,84 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
   WSYNC();
 }
 
+// The constraint instantiation needs two factorisations per step with the same sparsity: M (constraint rows, qacc_smooth)
+// and H = M + diag(armature + h damping) (the implicit-damping solve).  They are eliminated together, round by round:
+// one LDS round trip per tree level serves both, and the leaves-first sweep of the solve M x = rhs rides in the rounds
+// (when dof k is a pivot its x_k is complete: every proper ancestor i does x_i -= L[k][i] x_k).  A pivot at depth d has
+// entries in slots 0 .. d - 1 only, so a round moves ceil(d / 4) float4 groups, picked by a uniform switch (static
+// register indices).  On return HM / HR hold the unit-triangular factors, x the swept right-hand side of the M system.
+template <int MAXD>
+__device__ __forceinline__ void ldl_factor2(float* HM, float* HR, float* DVM, float* DVH, const DualRound* rounds, int nround, int lane,
+                                            bool isd, int ddepth, float& dinv_m, float& dinv_h, float& x) {
+  constexpr int RS = MAXD;
+  f2_t rm[MAXD / 2], rh[MAXD / 2];
+#pragma unroll
+  for (int d = 0; d < MAXD; d += 4) {
+    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
+    if (isd) { t = *(const float4*)(HM + lane * RS + d); u = *(const float4*)(HR + lane * RS + d); }
+    rm[d / 2] = f2_t{t.x, t.y}; rm[d / 2 + 1] = f2_t{t.z, t.w};
+    rh[d / 2] = f2_t{u.x, u.y}; rh[d / 2 + 1] = f2_t{u.z, u.w};
+  }
+  float dgm = isd ? HM[lane * RS + ddepth] : 1.f, dgh = isd ? HR[lane * RS + ddepth] : 1.f;
+  const cround_p RND = (cround_p)rounds;
+#define APPLY_PIVOT2(NG_, p_, am_) do { \
+    const float tkm_ = HM[(p_) * RS + ddepth], tkh_ = HR[(p_) * RS + ddepth]; const float dkm_ = DVM[p_], dkh_ = DVH[p_]; \
+    float4 km_[NG_], kh_[NG_]; \
+    _Pragma("unroll") for (int g = 0; g < NG_; g++) { km_[g] = *(const float4*)(HM + (p_) * RS + 4 * g); kh_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); } \
+    const float tm_ = mask_select(tkm_ * dkm_, am_), th_ = mask_select(tkh_ * dkh_, am_); \
+    const f2_t ntm_ = f2_t{-tm_, -tm_}, nth_ = f2_t{-th_, -th_}; \
+    _Pragma("unroll") for (int g = 0; g < NG_; g++) { \
+      rm[2 * g] = __builtin_elementwise_fma(ntm_, f2_t{km_[g].x, km_[g].y}, rm[2 * g]); \
+      rm[2 * g + 1] = __builtin_elementwise_fma(ntm_, f2_t{km_[g].z, km_[g].w}, rm[2 * g + 1]); \
+      rh[2 * g] = __builtin_elementwise_fma(nth_, f2_t{kh_[g].x, kh_[g].y}, rh[2 * g]); \
+      rh[2 * g + 1] = __builtin_elementwise_fma(nth_, f2_t{kh_[g].z, kh_[g].w}, rh[2 * g + 1]); } \
+    dgm = fmaf(-tm_, tkm_, dgm); dgh = fmaf(-th_, tkh_, dgh); \
+    x = fmaf(-tm_, bcast(x, p_), x); } while (0)
+#define ROUND_BODY2(NG_) do { \
+    if (isd) { \
+      _Pragma("unroll") for (int d = 0; d < 4 * NG_; d += 4) { \
+        *(float4*)(HM + lane * RS + d) = make_float4(rm[d / 2].x, rm[d / 2].y, rm[d / 2 + 1].x, rm[d / 2 + 1].y); \
+        *(float4*)(HR + lane * RS + d) = make_float4(rh[d / 2].x, rh[d / 2].y, rh[d / 2 + 1].x, rh[d / 2 + 1].y); } \
+      DVM[lane] = __builtin_amdgcn_rcpf(dgm); DVH[lane] = __builtin_amdgcn_rcpf(dgh); \
+    } \
+    WSYNC(); \
+    APPLY_PIVOT2(NG_, p0, a0); \
+    if (p1 >= 0) { APPLY_PIVOT2(NG_, p1, a1); APPLY_PIVOT2(NG_, p2, a2); } \
+    WSYNC(); } while (0)
+  {
+    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2, dep = RND[0].depth;
+    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
+#pragma unroll 1
+    for (int rd = 0; rd < nround; rd++) {
+      const int rn = rd + 1 < nround ? rd + 1 : rd;
+      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2, ndep = RND[rn].depth;
+      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2];
+      const int ng = (dep + 3) >> 2;
+      if (ng <= 1) ROUND_BODY2(1);
+      else if (MAXD >= 8 && ng == 2) ROUND_BODY2((MAXD >= 8 ? 2 : 1));
+      else if (MAXD >= 12 && ng == 3) ROUND_BODY2((MAXD >= 12 ? 3 : 1));
+      else if (MAXD >= 16 && ng == 4) ROUND_BODY2((MAXD >= 16 ? 4 : 1));
+      else if (MAXD >= 20 && ng == 5) ROUND_BODY2((MAXD >= 20 ? 5 : 1));
+      else if (MAXD >= 24 && ng == 6) ROUND_BODY2((MAXD >= 24 ? 6 : 1));
+      else if (MAXD >= 28 && ng == 7) ROUND_BODY2((MAXD >= 28 ? 7 : 1));
+      else ROUND_BODY2(MAXD / 4);
+      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; dep = ndep;
+    }
+  }
+#undef ROUND_BODY2
+#undef APPLY_PIVOT2
+  dinv_m = isd ? __builtin_amdgcn_rcpf(dgm) : 0.f;
+  dinv_h = isd ? __builtin_amdgcn_rcpf(dgh) : 0.f;
+  if (isd) {
+#pragma unroll
+    for (int d = 0; d < MAXD; d += 4) {
+      *(float4*)(HM + lane * RS + d) = make_float4(rm[d / 2].x * dinv_m, rm[d / 2].y * dinv_m, rm[d / 2 + 1].x * dinv_m, rm[d / 2 + 1].y * dinv_m);
+      *(float4*)(HR + lane * RS + d) = make_float4(rh[d / 2].x * dinv_h, rh[d / 2].y * dinv_h, rh[d / 2 + 1].x * dinv_h, rh[d / 2 + 1].y * dinv_h);
+    }
+  }
+  WSYNC();
+}
+
 // Root-first sweep x_d -= L[d][a] x_a over the proper ancestors a of d, a tree level at a time: every lane pulls x of
 // its ancestor at depth lvl with one ds_bpermute (lane table from the model: byte = 4 * lane) and applies its own L
 // entry for that depth (its row of HR, read once up front).  maxdep dependent steps instead of one per dof.
@@ -1280,15 +1358,15 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     }
     // ---- constraints (CONS instantiation only): qfrc_constraint from limits + plane contacts via PGS
     float qfrc_c = 0.f;
+    float dinv_h = 0.f;               // 1 / D of the factor of H
     if (CONS) {
       const float h = M.h;
-      // (1) factor M, qacc_smooth = M^-1 qfrc_smooth
+      // (1) factor M and H (together, see ldl_factor2), qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
-      {
-        ldl_factor<MAXD>(HM, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_m);
-      }
-      const float xs = ldl_solve<MAXD>(HM, qfrc, lane, isd, ddepth, dsub, nv, dinv_m, M.ancl1, M.maxdep1);
-      if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); }
+      float xs = isd ? qfrc : 0.f;
+      ldl_factor2<MAXD>(HM, HR, DI, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_m, dinv_h, xs);
+      xs = ldl_pull_sweep<MAXD>(HM, xs * dinv_m, isd ? lane : 0, isd, ddepth, M.ancl1, M.maxdep1);
+      if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); XV[lane] = dinv_h; }   // 1 / D of H waits in XV
       STAMP(12);  // factor M + qacc_smooth
       // (2) joint limit rows (mj_instantiateLimit): lane = dof, rows ordered by joint then side (-1, +1)
       const float4 lim = DTAB(dlo, 3);
@@ -1509,10 +1587,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     // ---- L + X: sparse L'DL of H = M + diag(armature + h*damping) and the solve H qacc = qfrc_smooth
     float my_qacc;
     {
-      float dinv_mine;
-      ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_mine);
+      if (CONS) dinv_h = isd ? XV[lane] : 0.f;          // factored together with M
+      else ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_h);
       STAMP(9);   // L
-      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_mine, M.ancl1, M.maxdep1);
+      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_h, M.ancl1, M.maxdep1);
     }
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)
