@@ -128,6 +128,7 @@ def other_workloads(n_envs, chunk, device):
     """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS) and configs[4] (eel + centipede buckets) on
     this GPU: env-steps/s over 500 timed steps after a warm-up (walking: 1000 steps, so that the animals stand and walk)."""
     import torch
+    from farms_mujoco_amd.simulation.buckets import BucketedSimulation
     res = {}
     for name, warm, steps in (('walk', 1000, 500), ('mixed', 300, 500)):
         if name == 'mixed':
@@ -135,17 +136,16 @@ def other_workloads(n_envs, chunk, device):
                     build_sim(n_envs - n_envs//2, 1 << 30, chunk, n_envs//2, device, morphology='centipede')[0]]
         else:
             sims = [build_sim(n_envs, 1 << 30, chunk, 0, device, workload='walk')[0]]
+        batch = BucketedSimulation(sims)
         for _ in range(warm//chunk):
-            for s_ in sims:
-                s_.step_fused(chunk)
+            batch.step_fused(chunk)
         torch.cuda.synchronize()
         evs = []
         t0 = time.perf_counter()
         for _ in range(steps//chunk):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for s_ in sims:
-                s_.step_fused(chunk)
+            batch.step_fused(chunk)
             e1.record()
             evs.append((e0, e1))
         torch.cuda.synchronize()
@@ -156,8 +156,8 @@ def other_workloads(n_envs, chunk, device):
         res[name] = {'value': n_envs*(steps//chunk)*chunk/dt, 'unit': 'env-steps/s', 'warmup': warm, 'steps': (steps//chunk)*chunk,
                      'launch_ms': {'min': float(ms.min()), 'median': float(np.median(ms)), 'max': float(ms.max())},
                      'config': 'BASELINE configs[3]: salamander-33 walking on a plane' if name == 'walk' else
-                               'BASELINE configs[4]: half eels, half centipedes, one bucket per morphology'}
-        del sims
+                               'BASELINE configs[4]: half eels, half centipedes, one bucket (launch) per morphology'}
+        del sims, batch
     return res
 
 
@@ -225,6 +225,9 @@ def main():
         sim, m, _ = build_sim(n_envs, n_it, chunk, env_offset=rank*n_envs, device=device, workload=args.workload)
         sims = [sim]
 
+    from farms_mujoco_amd.simulation.buckets import BucketedSimulation
+    batch = BucketedSimulation(sims)
+
     def run(n):
         """n steps in launches of `chunk` (the last one shorter), a HIP event pair on the launch stream around each."""
         done, evs = 0, []
@@ -232,8 +235,7 @@ def main():
             c = min(chunk, n - done)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            for s_ in sims:
-                s_.step_fused(c)
+            batch.step_fused(c)               # mixed: one launch per morphology bucket
             e1.record()
             evs.append((e0, e1, c))
             done += c

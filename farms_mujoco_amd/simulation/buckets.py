@@ -1,0 +1,50 @@
+"""Mixed-morphology batches (BASELINE configs[4]): one :class:`Simulation` per morphology ("bucket"), no padding.
+
+Every bucket is its own launch of the fused step kernel, with its own workgroup shape and LDS footprint; the buckets
+exchange nothing (independent environments), so there is no collective.  By default the launches follow each other on the
+caller's stream.  ``overlap=True`` forks the caller's stream into one HIP stream per bucket, launches the buckets side by
+side and joins them again (stream semantics for the caller unchanged: work queued before ``step_fused`` is visible to
+every bucket, work queued after it sees every bucket's result).  Measured on MI355X with 2048 eels + 2048 centipedes
+(round 2): 6.10 ms per 100 steps side by side against 5.60 ms back to back - the centipede workgroups take the whole LDS of a
+CU (8 x 19 KB), so the eel workgroups only trickle in next to them and two large kernels share the instruction caches -
+hence the default.
+"""
+import torch
+
+
+class BucketedSimulation:
+    """Drives several fused simulations (one per morphology) as one batch."""
+
+    def __init__(self, simulations, overlap: bool = False):
+        self.simulations = list(simulations)
+        self.overlap = bool(overlap)
+        assert self.simulations, 'at least one bucket'
+        self.device = self.simulations[0].physics.device
+        assert all(s.physics.device == self.device for s in self.simulations), 'buckets of one batch share a device'
+        self._streams = [torch.cuda.Stream(device=self.device) for _ in self.simulations] if self.device.type == 'cuda' else []
+        self._fork = torch.cuda.Event() if self._streams else None
+        self._join = [torch.cuda.Event() for _ in self._streams]
+
+    @property
+    def n_envs(self):
+        return sum(s.physics.n_envs for s in self.simulations)
+
+    def step_fused(self, n_steps: int) -> int:
+        """``n_steps`` iterations of every bucket, each in one launch, the launches overlapping on the device."""
+        if len(self.simulations) == 1 or not self._streams or not self.overlap:
+            return max(s.step_fused(n_steps) for s in self.simulations)
+        cur = torch.cuda.current_stream(self.device)
+        self._fork.record(cur)
+        done = 0
+        for sim, st, ev in zip(self.simulations, self._streams, self._join):
+            st.wait_event(self._fork)
+            with torch.cuda.stream(st):
+                done = max(done, sim.step_fused(n_steps))
+                ev.record(st)
+        for ev in self._join:
+            cur.wait_event(ev)
+        return done
+
+    def check_invalid_state(self):
+        for s in self.simulations:
+            s.physics.check_invalid_state()

@@ -110,6 +110,29 @@ def test_mixed_batch_bucketed(oracle):
     assert torch.equal(alone.task.data.sensors.links.array, sims[0][0].task.data.sensors.links.array)
 
 
+def test_buckets_side_by_side_equal_back_to_back():
+    """BucketedSimulation (one HIP stream per morphology bucket, launches overlapping on the device) logs bitwise the
+    rows and reaches bitwise the state of the same buckets stepped one after the other on the caller's stream."""
+    import torch
+    from farms_mujoco_amd.simulation.buckets import BucketedSimulation
+    T, ring = 120, 40
+    a = [_bucket_sim(maker, n, T, ring)[0] for maker, n in (('eel', 300), ('centipede', 200))]
+    b = [_bucket_sim(maker, n, T, ring)[0] for maker, n in (('eel', 300), ('centipede', 200))]
+    batch = BucketedSimulation(a, overlap=True)
+    assert batch.n_envs == 500
+    for _ in range(T // ring):
+        assert batch.step_fused(ring) == ring
+        for s in b:
+            s.step_fused(ring)
+    torch.cuda.synchronize()
+    batch.check_invalid_state()
+    for x, y in zip(a, b):
+        assert torch.equal(x.physics.data.qpos, y.physics.data.qpos) and torch.equal(x.physics.data.qvel, y.physics.data.qvel)
+        for k in ('links', 'joints', 'xfrc'):
+            assert torch.equal(getattr(x.task.data.sensors, k).array, getattr(y.task.data.sensors, k).array), k
+        assert x.task.iteration == T
+
+
 def test_full_size_config4_mixed_properties(oracle):
     """BASELINE configs[4] at the per-GPU size bench.py runs (2048 eels + 2048 centipedes, fused with drag, 300 steps,
     ring of 100): no warning bits; per bucket an 8-env sample matches the oracle (qpos, link rows, xfrc rows); envs with
