@@ -309,7 +309,7 @@ def main():
                          'frac_log_only': b['log']*n_envs*chunk/avg_launch_s/1e9/HBM_PEAK_GBS,
                          'traffic_note': 'HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
                                          f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}',
-                         'kernel': ('fmj_step_dual_kernel<true, MAXD> (two envs per wave)' if info['threads_per_env'] == 32
+                         'kernel': ('fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)' if info['threads_per_env'] == 32
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b['full'],

@@ -85,11 +85,10 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
-  // ---- two-envs-per-wave instantiation (fmj_dual.inc)
-  int dual_ok, dual_t0, dual_nM;       // eligible, translational dofs carried as scalars (3 with a free root), padded entry count
+  // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
+  int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
-  const float4* mtab2;                 // [dual_nM] entries (i, j >= dual_t0) in the mtab format
-  const struct DualRound* dual_rounds; // [dual_nround] elimination rounds of the two-env kernel (fmj_dual.inc)
+  const struct DualRound* dual_rounds; // [dual_nround] elimination rounds of the two-env kernel (fmj_dual2.inc)
   int dual_nround;
   const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
   int nround1;
@@ -164,8 +163,7 @@ struct fmj_ctx {
   int device, n_envs;
   DevModel dm;
   std::vector<void*> allocs;
-  size_t lds_bytes, lds_bytes_dual, lds_bytes_dual2;
-  int dual_gen;               // 2: fmj_dual2.inc (default), 1: fmj_dual.inc (FMJ_DUAL=1)
+  size_t lds_bytes, lds_bytes_dual2;
   int dual_wps;               // waves per SIMD the dual2 build is registered for: 4, or 3 when the batch cannot fill more (FMJ_WPS overrides)
   fmj_sensor_layout_t layout;
   // host copies needed later
@@ -409,7 +407,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
-  int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, CY, total;
+  int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, total;
   int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
   int YF, CF, nfl;                                                  // explicit pairs: fork parts of their rows, fork chain per row
 };
@@ -428,7 +426,6 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.XV = o; o += r4(nv);
   L.VT = o; o += 8;
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
-  L.CY = o; o += nb * 16;             // carried mjData fields of the last forward pass (fused loop)
   L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.SD = L.PO = L.AT = L.LC = L.CH = o; L.na = 0;
   L.YF = L.CF = o; L.nfl = 0;
   const int dead = 2 * nmax * 8 + r4(nb * 12);   // T/F, V/BUF, CI: not live between the M phase and the next step
@@ -902,7 +899,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   float* XV = lds + LL.XV;
   float* VT = lds + LL.VT;
   const uint8_t* JMP = (const uint8_t*)(lds + LL.ANC);   // [nb][anc_stride]: ancestor at distance 2^r
-  float* CY = lds + LL.CY;                               // [nb][16]: xpos(3) xquat(4) xipos(3) linvel(3) angvel(3)
   float* HM = lds + LL.HM;  float* YJ = lds + LL.YJ;  float* EPL = lds + LL.EP;  float* CT = lds + LL.CT;
   float* XS = lds + LL.XS;  float* QW = lds + LL.QW;  float* DI = lds + LL.DI;
   float* PO = lds + LL.PO;  float* LC = lds + LL.LC;  float* SD = lds + LL.SD;  float* CH = lds + LL.CH;
@@ -944,16 +940,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   float xf[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};     // world-frame external force / torque on this body
   float cy_actsum = 0.f;                            // carried motor torque (physics.py:510-524)
   if (FUSED) {
-    if (lane < nb) {
-      const float* p = glob(A.xpos) + (size_t)env * nb * 3 + lane * 3;
-      const float4 q = *(const float4*)(glob(A.xquat) + (size_t)env * nb * 4 + lane * 4);
-      const float* ip = glob(A.xipos) + (size_t)env * nb * 3 + lane * 3;
-      const float* sd = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (isb ? lane - 1 : 0);
-      *(float4*)(CY + lane * 16) = make_float4(p[0], p[1], p[2], q.x);
-      *(float4*)(CY + lane * 16 + 4) = make_float4(q.y, q.z, q.w, ip[0]);
-      *(float4*)(CY + lane * 16 + 8) = make_float4(ip[1], ip[2], sd[0], sd[1]);
-      *(float4*)(CY + lane * 16 + 12) = make_float4(sd[2], sd[3], sd[4], sd[5]);
-    }
     const float4 dp = DTAB(dl, 1);
     if (isd && dp.w != 0.f) {
       const int4 da = DTABI(dl, 2);
@@ -971,6 +957,20 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   // finds the bad value on and in later launches until the caller clears its status word.
   bool frozen = (gptr(A.status)[env] & FMJ_WARN_FREEZE) != 0 || __any((warn & FMJ_WARN_FREEZE) != 0);
   int steps_done = 0;
+  // The fields of the last forward pass are not carried through LDS: the links row of iteration it + 1 and its drag
+  // (ExperimentTask.before_step, reference task.py:168-186) are emitted by the step that computes them (step it); the row of
+  // the launch's first iteration comes from the fields the caller hands over.
+  if (FUSED && !frozen && A.n_steps > 0) {
+    const int cl = lane < nb ? lane : 0;
+    const float* p = glob(A.xpos) + (size_t)env * nb * 3 + cl * 3;
+    const float4 q = *(const float4*)(glob(A.xquat) + (size_t)env * nb * 4 + cl * 4);
+    const float* ip = glob(A.xipos) + (size_t)env * nb * 3 + cl * 3;
+    const float* sd = glob(A.sensordata) + (size_t)env * M.nsensordata + 6 * (isb ? lane - 1 : 0);
+    const int4 ci2 = BTABI(bl, 8);
+    const q4 cq = {q.x, q.y, q.z, q.w};
+    emit_links_and_drag(M, A, env, A.iteration0, isb, false, ci2.z, ci2.w, mk3(p[0], p[1], p[2]), cq, mk3(ip[0], ip[1], ip[2]),
+                        mk3(sd[0], sd[1], sd[2]), mk3(sd[3], sd[4], sd[5]), xf);
+  }
   WSYNC();
 #ifdef FMJ_STAMPS
   float stamp_acc[NSTAMP];
@@ -990,15 +990,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const bool last = step == A.n_steps - 1;
     const int blo = opaque(bl), dlo = opaque(dl);
     // ============ before_step (reference task.py:168-186) ============
-    if (FUSED) {      // links row + drag from the fields the last forward pass left (carried in LDS)
-      const int4 ci2 = BTABI(blo, 8);
-      const int cl = lane < nb ? lane : 0;
-      const float4 c0 = *(const float4*)(CY + cl * 16), c1 = *(const float4*)(CY + cl * 16 + 4);
-      const float4 c2 = *(const float4*)(CY + cl * 16 + 8), c3 = *(const float4*)(CY + cl * 16 + 12);
-      const q4 cq = {c0.w, c1.x, c1.y, c1.z};
-      emit_links_and_drag(M, A, env, it, isb, false, ci2.z, ci2.w, mk3(c0.x, c0.y, c0.z), cq, mk3(c1.w, c2.x, c2.y),
-                          mk3(c2.z, c2.w, c3.x), mk3(c3.y, c3.z, c3.w), xf);
-    }
     STAMP(0);   // emit links + drag
     if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list
       const int index = it % A.buffer_size;
@@ -1177,11 +1168,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     // ---- sensors of this (pre-integration) state; they are next iteration's link data (mj_step lag)
     {
       const v3 linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
-      if (FUSED && lane < nb) {
-        *(float4*)(CY + lane * 16) = make_float4(xp.x, xp.y, xp.z, xq.w);
-        *(float4*)(CY + lane * 16 + 4) = make_float4(xq.x, xq.y, xq.z, xi.x);
-        *(float4*)(CY + lane * 16 + 8) = make_float4(xi.y, xi.z, linvel.x, linvel.y);
-        *(float4*)(CY + lane * 16 + 12) = make_float4(linvel.z, cv.r.x, cv.r.y, cv.r.z);
+      if (FUSED && !last) {      // next iteration's links row and drag (xf is consumed above, in this step's F)
+        const int4 ci2 = BTABI(blo, 8);
+        emit_links_and_drag(M, A, env, it + 1, isb, false, ci2.z, ci2.w, xp, xq, xi, linvel, cv.r, xf);
       }
       if (last && lane < nb) {
         float* p = glob(A.xpos) + (size_t)env * nb * 3 + lane * 3; p[0] = xp.x; p[1] = xp.y; p[2] = xp.z;
@@ -1655,7 +1644,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 
 #undef M
 #undef A
-#include "fmj_dual.inc"
 #include "fmj_dual2.inc"
 
 // ---------------------------------------------------------------------------------------------
@@ -1668,7 +1656,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
-  if (dual) return fused ? (void*)fmj_step_dual_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_dual_kernel<false, FMJ_TU_MAXD>;
   if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
@@ -1821,9 +1808,9 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons ? (c->dm.npair > 0 ? 2 : 1) : 0, 0); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
-  if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc / fmj_dual.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_gen == 2 && c->dual_wps == 3 ? 3 : c->dual_gen);
-    hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual, (hipStream_t)stream, c->dm, A);
+  if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 3 ? 3 : 2);
+    hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual2, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
     return FMJ_OK;
@@ -2180,13 +2167,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     const char* envv = getenv("FMJ_DUAL");
     D.dual_t0 = t0;
     D.dual_ok = !cons && nb <= 32 && nv - t0 <= 32 && !(envv && envv[0] == '0');
-    std::vector<float4> mtab2;
-    { int ee = 0; for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { if (i >= t0 && j >= t0) mtab2.push_back(mtab[ee]); ee++; } }
-    while (mtab2.size() % 32) mtab2.push_back(f4(0, 0, 0, 0));
-    if (mtab2.empty()) mtab2.assign(32, f4(0, 0, 0, 0));
-    D.dual_nM = (int)mtab2.size();
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
-    UP(mtab2, mtab2);
     {   // elimination rounds of the one-env kernel (lane = dof): dofs grouped by depth, deepest first, <= 3 per round
       std::vector<DualRound> rounds;
       std::vector<unsigned long long> ancm(nv, 0ull), descm(nv, 0ull);
@@ -2299,9 +2280,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   LdsLayout L = lds_layout(nb, nv, nq, D.rs, D.anc_stride, D.cons, D.maxefc, D.max_contacts, D.nvs, D.npair);
   D.nfl = L.nfl;
   c->lds_bytes = (size_t)L.total * sizeof(float);
-  c->lds_bytes_dual = D.dual_ok ? (size_t)(2 * lds_layout(nb, nv, nq, D.rs, D.anc_stride).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
   c->lds_bytes_dual2 = D.dual_ok ? (size_t)(2 * lds2_layout(nb, nv, nq, D.rs, D.dual_t0).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
-  { const char* envv = getenv("FMJ_DUAL"); c->dual_gen = (envv && envv[0] == '1') ? 1 : 2; }
   {
     hipDeviceProp_t prop;
     int n_cu = 256;
@@ -2327,7 +2306,7 @@ int fmj_get_sensor_layout(const fmj_ctx* c, fmj_sensor_layout_t* out) {
 
 int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threads_per_env) {
   if (!c) return set_err(FMJ_ERR_ARG, "fmj_kernel_info: NULL ctx");
-  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)(c->dm.dual_ok ? (c->dual_gen == 2 ? c->lds_bytes_dual2 : c->lds_bytes_dual) / 2 : c->lds_bytes);
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)(c->dm.dual_ok ? c->lds_bytes_dual2 / 2 : c->lds_bytes);
   if (threads_per_env) *threads_per_env = c->dm.dual_ok ? 32 : 64;   // the integrating step packs two envs per wave when it can
   return FMJ_OK;
 }
