@@ -1,21 +1,23 @@
 // fmj_hip.hip — MI355X (gfx950) implementation of include/fmj.h.
 //
-// One wavefront (64 lanes) owns one environment.  Lanes play two roles, "lane = body" and
-// "lane = dof"; cross-lane data goes through LDS, everything else stays in registers.  There is
-// no MFMA: the largest "matrix" is the nv x nv (<= 64) tree-sparse joint-space inertia.
+// One wavefront (64 lanes) owns one environment here (models without constraints that fit half a wave run two per wave:
+// fmj_dual2.inc).  Lanes play two roles, "lane = body" and "lane = dof"; cross-lane data goes through ds_bpermute, DPP,
+// v_readlane and LDS, everything else stays in registers.  There is no MFMA: the largest "matrix" is the nv x nv (<= 64)
+// tree-sparse joint-space inertia.  Kernel arguments are read through the kernarg segment where they are used.
 //
 // Per step (mj_step semantics, MuJoCo's documented pipeline restricted to what reference
 // farms_mujoco/simulation/mjcf.py emits):
-//   K  local joint transforms (lane=body) -> LDS; every lane composes its root->body chain
-//   C  subtree CoM by wave reduction; cinert (lane=body), cdof (lane=body -> dof slots)
-//   V  per-body joint velocity vJ -> LDS; every lane walks its chain: cvel, cacc (no cdof_dot
-//      array: cdof_dot*qvel = cvel_parent x vJ by linearity of the motion cross product)
-//   F  body force f = I a + v x* I v - F_ext (lane=body) -> LDS
-//   S  subtree sums over the contiguous DFS id range: composite inertia, accumulated force
+//   K  local joint transforms (lane=body), composed along the chains by pointer jumping (ds_bpermute)
+//   C  subtree CoM by wave reduction; cinert (lane=body), cdof (lane=body -> dof slots in LDS)
+//   V  joint velocity vJ; chain sums by pointer jumping: cvel, cacc (no cdof_dot array:
+//      cdof_dot*qvel = cvel_parent x vJ by linearity of the motion cross product)
+//   F  body force f = I a + v x* I v - F_ext (lane=body); next iteration's links row and drag
+//   S  subtree sums over the contiguous DFS id range (fp64 DPP prefix-sum differences): composite inertia, force
 //   Q  qfrc_smooth (lane=dof): passive + actuation - cdof . f_subtree
-//   M  H = M + diag(armature + h*damping): one entry per lane-round, depth-indexed rows in LDS
-//   L  L'DL: lane i owns row i in registers; step k broadcasts row k through LDS
-//   X  two triangular sweeps with v_readlane broadcasts; semi-implicit Euler; sensors
+//   M  row i of M born in the registers of lane = dof i (one entry per depth of its chain)
+//   L  L'DL by rounds of unrelated dofs, rows in registers, pivot rows through LDS; with constraints M and
+//      H = M + diag(armature + h*damping) are factored together, then limits / contacts / PGS (fmj_cons_rows.inc)
+//   X  two triangular sweeps (v_readlane, ds_bpermute); semi-implicit Euler; sensors
 //
 // Fused mode wraps this with the reference's before_step work (task.py:168-186):
 // physics2data row write (physics.py:527-545), SwimmingHandler.step (drag.pyx:389-411) and the
@@ -54,7 +56,7 @@ struct DualRound {
 };
 
 struct DevModel {
-  int nbody, nv, nq, nu, njnt, nM, nMpad;
+  int nbody, nv, nq, nu, njnt, nM;
   int max_bdepth;     // pointer-jumping rounds = ceil(log2(longest root->body chain))
   int max_subsize;    // largest subtree (bodies)
   int rs;             // row stride of Hrow (multiple of 4, >= max dof depth + 1)
@@ -67,7 +69,6 @@ struct DevModel {
   const float4* btab;         // [64][BT_STRIDE]
   const float4* dtab;         // [64][DT_STRIDE]
   const float4* atab;         // [nu][AT_STRIDE]
-  const float4* mtab;         // [nMpad] (entry bits i | j<<6 | depth<<12 | body(i)<<18 | valid<<24, armature + h*damping, armature, -)
   const float4* stab;         // [ns][ST_STRIDE]
   const float4* gtab;         // [ngeom][GT_STRIDE]
   const float4* ptab;         // [nplane][PT_STRIDE]
@@ -131,7 +132,6 @@ __device__ __forceinline__ float2 ldg2f(const float* p) { const vf2_t v = *(cons
 #define DTAB(d, k) ldg4(M.dtab, (unsigned)(d) * DT_STRIDE + (k))
 #define DTABI(d, k) as_int4(DTAB(d, k))
 #define ATAB(a, k) ldg4(M.atab, (unsigned)(a) * AT_STRIDE + (k))
-#define MTAB(e) ldg4(M.mtab, (unsigned)(e))
 #define STAB(i, k) ldg4(M.stab, (unsigned)(i) * ST_STRIDE + (k))
 #define GTAB(g, k) ldg4(M.gtab, (unsigned)(g) * GT_STRIDE + (k))
 #define GTABI(g, k) as_int4(GTAB(g, k))
@@ -407,7 +407,7 @@ __host__ __device__ inline int r4(int x) { return (x + 3) & ~3; }
 
 // LDS layout in floats; shared by host (size) and device (carve)
 struct LdsLayout {
-  int P1, P2, CI, CD, HR, QP, QV, XV, VT, ANC, total;
+  int P1, CI, CD, HR, QP, QV, XV, VT, ANC, total;
   int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
   int YF, CF, nfl;                                                  // explicit pairs: fork parts of their rows, fork chain per row
 };
@@ -420,7 +420,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   const int nmax = nb > nv ? nb : nv;
   int o = 0;
   // every region starts on a 16-byte boundary (float4 LDS accesses; a misaligned ds_read_b128 is split and stalls)
-  L.HR = o; o += nv * rs;             // depth-indexed rows of H = M + h B, then its L'DL
+  L.HR = o; if (cons) o += nv * rs;   // depth-indexed rows of the L'DL of H = M + h B (without constraints they overlay CD / F / CI, see below)
   L.QP = o; o += r4(nq);
   L.QV = o; o += r4(nv);
   L.XV = o; o += r4(nv);
@@ -428,7 +428,7 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
   L.ANC = o; o += r4(r4(nb * anc_stride) / 4);
   L.HM = L.YJ = L.EP = L.CT = L.XS = L.WW = L.QW = L.DI = L.SD = L.PO = L.AT = L.LC = L.CH = o; L.na = 0;
   L.YF = L.CF = o; L.nfl = 0;
-  const int dead = 2 * nmax * 8 + r4(nb * 12);   // T/F, V/BUF, CI: not live between the M phase and the next step
+  const int dead = nmax * 8 + r4(nb * 12);       // F, CI: not live between the M phase and the next step
   if (cons) {
     L.HM = o; o += nv * rs;           // rows of M, then its L'DL
     L.CT = o; o += maxcon * 16;       // contacts: pos(3) normal(3) t1(3) t2(3) dist mu geom plane
@@ -448,12 +448,18 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
       L.CF = o; o += r4((maxefc + 3) / 4);        // uint8 per row: last dof of the fork's chain + 1 (0: no fork)
     }
   }
+  const int r1 = o;
   L.CD = o; o += nv * 8;              // cdof
-  L.P1 = o; o += nmax * 8;            // T (local transforms) -> F (body force / subtree force)
-  L.P2 = o; o += nmax * 8;            // V (joint velocity)   -> BUF (crb * cdof)
-  L.CI = o; o += r4(nb * 12);         // cinert -> composite inertia
+  L.P1 = o; o += nmax * 8;            // F (body force -> subtree force)
+  L.CI = o; o += r4(nb * 12);         // subtree inertia about its own CoM (6), subtree CoM (3), subtree mass
+  if (!cons) {
+    // the rows of H are born in registers (M phase) and only reach LDS when the factorisation publishes them: CD / F / CI
+    // are dead by then
+    L.HR = r1;
+    if (r1 + nv * rs > o) o = r1 + nv * rs;
+  }
   if (cons) {
-    // the compact constraint rows (na x rs) overlay T/F, V/BUF and CI, which are dead from the Jacobian rows on
+    // the compact constraint rows (na x rs) overlay F and CI, which are dead from the Jacobian rows on
     L.YJ = L.P1;
     const int extra = L.na * rs - dead;
     L.AT = o; if (extra > 0) o += r4(extra);
@@ -511,16 +517,10 @@ typedef const DualRound __attribute__((address_space(4)))* cround_p;   // consta
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
 template <int MAXD>
-__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth, float& dinv_mine) {
+__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth,
+                                           f2_t (&r)[MAXD / 2], float diag, float& dinv_mine) {
   constexpr int RS = MAXD;
-  f2_t r[MAXD / 2];                                // row in registers as float pairs: the update is v_pk_fma_f32
-#pragma unroll
-  for (int d = 0; d < MAXD; d += 4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (isd) t = *(const float4*)(HR + lane * RS + d);
-    r[d / 2] = f2_t{t.x, t.y}; r[d / 2 + 1] = f2_t{t.z, t.w};
-  }
-  float diag = isd ? HR[lane * RS + ddepth] : 1.f;
+  // r = the lane's row in registers as float pairs (the update is v_pk_fma_f32), diag its diagonal entry (M phase)
   // Rounds of unrelated dofs (same depth, deepest level first, <= 3 per round; records built at fmj_create and read
   // through the scalar cache one round ahead): every lane publishes its working row and 1/diag (DV) - only the
   // members' are read, theirs are final - and every proper ancestor i of a member k (uniform lane mask) does
@@ -577,17 +577,12 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
 // register indices).  On return HM / HR hold the unit-triangular factors, x the swept right-hand side of the M system.
 template <int MAXD>
 __device__ __forceinline__ void ldl_factor2(float* HM, float* HR, float* DVM, float* DVH, const DualRound* rounds, int nround, int lane,
-                                            bool isd, int ddepth, float& dinv_m, float& dinv_h, float& x) {
+                                            bool isd, int ddepth, f2_t (&rh)[MAXD / 2], float dgm, float dgh, float& dinv_m, float& dinv_h, float& x) {
   constexpr int RS = MAXD;
-  f2_t rm[MAXD / 2], rh[MAXD / 2];
+  // rh = the lane's row of M (M phase; M and H differ on the diagonal only: dgm, dgh), worked on in place for H
+  f2_t rm[MAXD / 2];
 #pragma unroll
-  for (int d = 0; d < MAXD; d += 4) {
-    float4 t = make_float4(0.f, 0.f, 0.f, 0.f), u = t;
-    if (isd) { t = *(const float4*)(HM + lane * RS + d); u = *(const float4*)(HR + lane * RS + d); }
-    rm[d / 2] = f2_t{t.x, t.y}; rm[d / 2 + 1] = f2_t{t.z, t.w};
-    rh[d / 2] = f2_t{u.x, u.y}; rh[d / 2 + 1] = f2_t{u.z, u.w};
-  }
-  float dgm = isd ? HM[lane * RS + ddepth] : 1.f, dgh = isd ? HR[lane * RS + ddepth] : 1.f;
+  for (int d = 0; d < MAXD / 2; d++) rm[d] = rh[d];
   const cround_p RND = (cround_p)rounds;
 #define APPLY_PIVOT2(NG_, p_, am_) do { \
     const float tkm_ = HM[(p_) * RS + ddepth], tkh_ = HR[(p_) * RS + ddepth]; const float dkm_ = DVM[p_], dkh_ = DVH[p_]; \
@@ -889,8 +884,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
   const LdsLayout LL = lds_layout(nb, nv, nq, RS, M.anc_stride, CONS ? 1 : 0, M.maxefc, M.max_contacts, M.nvs, M.npair);
-  float* T = lds + LL.P1;  float* F = T;       // T (transforms) -> W (acceleration scan) -> F (body force)
-  float* V = lds + LL.P2;  float* BUF = V;     // V (velocity scan) -> BUF (I w, m v)
+  float* F = lds + LL.P1;                      // body force -> subtree force
   float* CI = lds + LL.CI;
   float* CD = lds + LL.CD;
   float* HR = lds + LL.HR;
@@ -916,6 +910,11 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 
   // ---- load tables + state -------------------------------------------------------------------------
   int warn = 0;
+  // The step reads LDS words it never wrote (record pads; row slots of the factorisation no round has published yet, under
+  // masks that select them away but still multiply them by zero): they must hold finite values, not what the previous
+  // workgroup left there.
+  for (int i = lane * 4; i < LL.total; i += 256) *(float4*)(lds + i) = make_float4(0.f, 0.f, 0.f, 0.f);
+  WSYNC();
   {
     uint32_t* jw = (uint32_t*)(lds + LL.ANC);
     const int nw = r4(nb * M.anc_stride) / 4;
@@ -1226,8 +1225,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     }
     WSYNC();
     STAMP(6);   // S
-    for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HR + i) = make_float4(0.f, 0.f, 0.f, 0.f);   // see ldl_factor
-    if (CONS) for (int i = lane * 4; i < nv * RS; i += 256) *(float4*)(HM + i) = make_float4(0.f, 0.f, 0.f, 0.f);
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
     float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
@@ -1235,17 +1232,18 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const int4 d_act = DTABI(dlo, 2);               // first actuator, count, joint sensor slot
     const int d_qadr = __float_as_int(d_prm.z);
     const bool d_scalar = isd && d_prm.w != 0.f;
+    s6 cd = {mk3(0.f, 0.f, 0.f), mk3(0.f, 0.f, 0.f)}, bf = cd;     // this dof's cdof; (I_s w_i, m v_i(s)), s = CoM of the subtree it moves
+    v3 sc = mk3(0.f, 0.f, 0.f);                                    // s relative to the tree CoM
     if (isd) {
       const int body = DTABI(dlo, 0).x;
-      const s6 cd = lds_get6(CD + lane * 8);
+      cd = lds_get6(CD + lane * 8);
       {
         const float4 a = *(const float4*)(CI + body * 12), b = *(const float4*)(CI + body * 12 + 4);
         const float2 c = *(const float2*)(CI + body * 12 + 8);
-        const v3 vs = add3(cd.l, cross(cd.r, sub3(mk3(b.z, b.w, c.x), com)));   // velocity of the subtree CoM per unit dof rate
-        s6 bf;
+        sc = sub3(mk3(b.z, b.w, c.x), com);
+        const v3 vs = add3(cd.l, cross(cd.r, sc));                 // velocity of the subtree CoM per unit dof rate
         bf.r = mk3(a.x * cd.r.x + a.w * cd.r.y + b.x * cd.r.z, a.w * cd.r.x + a.y * cd.r.y + b.y * cd.r.z, b.x * cd.r.x + b.y * cd.r.y + a.z * cd.r.z);
         bf.l = scl3(vs, c.y);
-        lds_put6(BUF + lane * 8, bf);
       }
       const float qd = QV[lane];
       qfrc = -d_prm.y * qd - s6dot(cd, lds_get6(F + body * 8));
@@ -1300,50 +1298,47 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     }
     WSYNC();
     STAMP(7);   // Q
-    // ---- M: H entries, one per lane per round: M_ij = w_j . (I_s w_i) + v_j(s) . (m v_i(s)), s = subtree CoM of dof i's body
+    // ---- M: row i of M (lane = dof i), one entry per depth of the chain root -> i, born in registers:
+    //      M[i][j] = w_j . (I_s w_i) + v_j(s) . (m v_i(s)), s = CoM of the subtree dof i moves, j = ancestor of i at that depth;
+    //      v_j(s) = v_j + w_j x sc, so M[i][j] = w_j . (I_s w_i + sc x p_i) + v_j . p_i with p_i = m v_i(s): the bracket gi is
+    //      the lane's own and an entry costs two dot products.  Slots at and past the lane's own depth hold finite values
+    //      that are never read as matrix entries (beyond the chain the table names the lane itself); the diagonals live in
+    //      hdg_m (+ armature) and hdg_h (+ armature + h damping).  Lanes without a dof have cd = 0: their rows are zero.
+    f2_t hrow[MAXD / 2];
+    float hdg_m, hdg_h;
     {
-      constexpr int MAXR = 8;                         // table entries for up to 8 rounds are fetched up front
-      uint32_t tt[MAXR]; float ta[MAXR];
+      const v3 gi = add3(bf.r, cross(sc, bf.l));
+      const float mii = dot3(cd.r, gi) + dot3(cd.l, bf.l);
+      hdg_m = isd ? mii + d_prm.x : 1.f;
+      hdg_h = isd ? mii + (d_prm.x + M.h * d_prm.y) : 1.f;
+      const int maxdep = M.maxdep1;
 #pragma unroll
-      for (int rr = 0; rr < MAXR; rr++) {
-        const int e = lane + 64 * rr;
-        tt[rr] = e < M.nMpad ? __float_as_uint_(MTAB(e).x) : 0u;
-        ta[rr] = e < M.nMpad ? MTAB(e).y : 0.f;
-      }
+      for (int g = 0; g < MAXD / 4; g++) {
+        const uint32_t ab = gptr(M.ancl1)[(unsigned)dlo * (MAXD / 4) + g];
 #pragma unroll
-      for (int rr = 0; rr < MAXR; rr++) {
-        const uint32_t t = tt[rr];
-        if (t >> 24) {
-          const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
-          const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
-          const float2 sxy = *(const float2*)(CI + body * 12 + 6);
-          const float sz = CI[body * 12 + 8];
-          const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
-          const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
-          HR[i * RS + dep] = mij + ta[rr];
-          if (CONS) HM[i * RS + dep] = mij + MTAB(lane + 64 * rr).z;
-        }
-      }
-#pragma unroll 1
-      for (int e = lane + 64 * MAXR; e < M.nMpad; e += 64) {     // models with more than 512 entries
-        const uint32_t t = __float_as_uint_(MTAB(e).x);
-        if (t >> 24) {
-          const int i = t & 0x3f, j = (t >> 6) & 0x3f, dep = (t >> 12) & 0x3f, body = (t >> 18) & 0x3f;
-          const s6 cdj = lds_get6(CD + j * 8), bf = lds_get6(BUF + i * 8);
-          const float2 sxy = *(const float2*)(CI + body * 12 + 6);
-          const float sz = CI[body * 12 + 8];
-          const v3 vj = add3(cdj.l, cross(cdj.r, sub3(mk3(sxy.x, sxy.y, sz), com)));
-          const float mij = dot3(cdj.r, bf.r) + dot3(vj, bf.l);
-          HR[i * RS + dep] = mij + MTAB(e).y;
-          if (CONS) HM[i * RS + dep] = mij + MTAB(e).z;
+        for (int k = 0; k < 4; k++) {
+          const int d = 4 * g + k;
+          float mij = 0.f;
+          if (d <= maxdep) {                        // uniform test, static register index
+            const int al = (int)((ab >> (8 * k)) & 0xffu) >> 2;            // lane = dof of the ancestor at depth d
+            const s6 cdj = lds_get6(CD + al * 8);
+            mij = dot3(cdj.r, gi) + dot3(cdj.l, bf.l);
+          }
+          if (k & 1) hrow[d / 2].y = mij; else hrow[d / 2].x = mij;
         }
       }
     }
-    WSYNC();
+    WSYNC();                                        // without constraints the published rows overlay CD / F / CI from here
     STAMP(8);   // M
-    if (!FUSED && A.dbg_H) {      // fmj_forward_debug: the assembled rows and the right-hand side, before any factorisation
-      for (int i = lane; i < nv * RS; i += 64) gptr(A.dbg_H)[(size_t)env * nv * RS + i] = HR[i];
-      if (isd) gptr(A.dbg_qfrc)[(size_t)env * nv + lane] = qfrc;
+    if (!FUSED && A.dbg_H) {      // fmj_forward_debug: the assembled rows of H and the right-hand side, before any factorisation
+      if (isd) {
+#pragma unroll
+        for (int d = 0; d < MAXD; d++) {
+          const float v = (d & 1) ? hrow[d / 2].y : hrow[d / 2].x;
+          gptr(A.dbg_H)[((size_t)env * nv + lane) * RS + d] = d < ddepth ? v : (d == ddepth ? hdg_h : 0.f);
+        }
+        gptr(A.dbg_qfrc)[(size_t)env * nv + lane] = qfrc;
+      }
     }
     // ---- constraints (CONS instantiation only): qfrc_constraint from limits + plane contacts via PGS
     float qfrc_c = 0.f;
@@ -1353,7 +1348,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (1) factor M and H (together, see ldl_factor2), qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
       float xs = isd ? qfrc : 0.f;
-      ldl_factor2<MAXD>(HM, HR, DI, XV, M.rounds1, M.nround1, lane, isd, ddepth, dinv_m, dinv_h, xs);
+      ldl_factor2<MAXD>(HM, HR, DI, XV, M.rounds1, M.nround1, lane, isd, ddepth, hrow, hdg_m, hdg_h, dinv_m, dinv_h, xs);
       xs = ldl_pull_sweep<MAXD>(HM, xs * dinv_m, isd ? lane : 0, isd, ddepth, M.ancl1, M.maxdep1);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); XV[lane] = dinv_h; }   // 1 / D of H waits in XV
       STAMP(12);  // factor M + qacc_smooth
@@ -1577,7 +1572,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     float my_qacc;
     {
       if (CONS) dinv_h = isd ? XV[lane] : 0.f;          // factored together with M
-      else ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, dinv_h);
+      else ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, hrow, hdg_h, dinv_h);
       STAMP(9);   // L
       my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_h, M.ancl1, M.maxdep1);
     }
@@ -2032,20 +2027,13 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     d_act[d0] = make_int4(first, cnt, sj, 0);
     sj++;
   }
-  // M entry table
-  int nMpad = ((m->nM + 63) / 64) * 64;
-  std::vector<uint32_t> m_tab(nMpad, 0); std::vector<float> m_add(nMpad, 0.f);
+  // the caller's sparse layout of M (mjModel dof_Madr / nM) must describe the same tree
   int e = 0;
   for (int i = 0; i < nv; i++) {
     if (m->dof_Madr[i] != e) { fmj_destroy(c); return set_err(FMJ_ERR_ARG, "fmj_create: dof_Madr inconsistent"); }
-    for (int j = i; j >= 0; j = m->dof_parentid[j]) {
-      m_tab[e] = (uint32_t)i | ((uint32_t)j << 6) | ((uint32_t)ddepth[j] << 12) | ((uint32_t)m->dof_bodyid[i] << 18) | (1u << 24);
-      if (i == j) m_add[e] = (float)(m->dof_armature[i] + m->timestep * m->dof_damping[i]);
-      e++;
-    }
+    for (int j = i; j >= 0; j = m->dof_parentid[j]) e++;
   }
   if (e != m->nM) { fmj_destroy(c); return set_err(FMJ_ERR_ARG, "fmj_create: nM inconsistent"); }
-  D.nMpad = nMpad;
   c->h_b_info2.assign((int*)b_info2.data(), (int*)b_info2.data() + 64 * 4);
   c->h_d_info.assign((int*)d_info.data(), (int*)d_info.data() + 64 * 4);
 
@@ -2078,8 +2066,6 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
   D.pgs_scale = (float)(1.0 / ((m->meaninertia > 0 ? m->meaninertia : 1.0) * (nv > 1 ? nv : 1)));
-  std::vector<float> m_arm(nMpad, 0.f);
-  { int ee = 0; for (int i = 0; i < nv; i++) for (int j = i; j >= 0; j = m->dof_parentid[j]) { if (i == j) m_arm[ee] = (float)m->dof_armature[i]; ee++; } }
   std::vector<int> d_parent(64, -1);
   for (int d = 0; d < nv; d++) d_parent[d] = m->dof_parentid[d];
   std::vector<int4> g_info(m->ngeom ? m->ngeom : 1); std::vector<float4> g_size(g_info.size()), g_pos(g_info.size()), g_quat(g_info.size()), g_sol0(g_info.size()), g_sol1(g_info.size());
@@ -2136,9 +2122,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     int4 act = d_act[d]; act.w = d_parent[d];
     t[0] = i4f(d_info[d]); t[1] = d_prm[d]; t[2] = i4f(act); t[3] = d_lim[d]; t[4] = d_sol0[d]; t[5] = d_sol1[d];
   }
-  std::vector<float4> atab((a_src.size() ? a_src.size() : 1) * AT_STRIDE, f4(0, 0, 0, 0)), mtab(nMpad ? nMpad : 1, f4(0, 0, 0, 0));
+  std::vector<float4> atab((a_src.size() ? a_src.size() : 1) * AT_STRIDE, f4(0, 0, 0, 0));
   for (size_t a = 0; a < a_src.size(); a++) { atab[a * AT_STRIDE] = a_prm[a]; atab[a * AT_STRIDE + 1] = a_lim[a]; atab[a * AT_STRIDE + 2] = make_float4(ibits(a_src[a]), 0.f, 0.f, 0.f); }
-  for (int e2 = 0; e2 < nMpad; e2++) mtab[e2] = make_float4(ibits((int)m_tab[e2]), m_add[e2], m_arm[e2], 0.f);
   std::vector<float4> gtab(g_info.size() * GT_STRIDE), ptab(p_plane.size() * PT_STRIDE);
   for (size_t g = 0; g < g_info.size(); g++) { float4* t = &gtab[g * GT_STRIDE]; t[0] = i4f(g_info[g]); t[1] = g_size[g]; t[2] = g_pos[g]; t[3] = g_quat[g]; t[4] = g_sol0[g]; t[5] = g_sol1[g]; }
   for (size_t p = 0; p < p_plane.size(); p++) { ptab[p * PT_STRIDE] = p_plane[p]; ptab[p * PT_STRIDE + 1] = p_prm[p]; ptab[p * PT_STRIDE + 2] = p_hq[p]; ptab[p * PT_STRIDE + 3] = p_hs[p]; }
@@ -2161,7 +2146,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     UP(hf, hf_data);
   }
   c->h_atab = atab; c->a_src = a_src;
-  UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(mtab, mtab); UP(gtab, gtab); UP(ptab, ptab);
+  UP(c->h_btab, btab); UP(c->h_dtab, dtab); UP(atab, atab); UP(gtab, gtab); UP(ptab, ptab);
   {   // two envs per wave: bodies and the dofs minus a free root's translational dofs must fit 32 lanes
     const int t0 = D.root_free ? 3 : 0;
     const char* envv = getenv("FMJ_DUAL");
