@@ -516,6 +516,12 @@ __device__ __forceinline__ float mask_select(const float v, const unsigned long 
 typedef const DualRound __attribute__((address_space(4)))* cround_p;   // constant address space: uniform index -> s_load
 
 typedef float f2_t __attribute__((ext_vector_type(2)));
+// acc -= t * v on a float pair, in place.  Tied operands: the rows of the factorisation are updated inside the branches of a
+// uniform switch (groups per round); left to the compiler each branch puts its results where it likes and every join costs a
+// copy of the whole register row (~36 v_mov per round measured), with a tied accumulator the row never moves.
+__device__ __forceinline__ void pk_fnma(f2_t& acc, const f2_t tt, const f2_t v) {
+  asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(tt), "v"(v));
+}
 template <int MAXD>
 __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth,
                                            f2_t (&r)[MAXD / 2], float diag, float& dinv_mine) {
@@ -533,10 +539,10 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
     float4 rk_[NG_]; \
     _Pragma("unroll") for (int g = 0; g < NG_; g++) rk_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); \
     const float t_ = mask_select(tk_ * dki_, am_); \
-    const f2_t nt_ = f2_t{-t_, -t_}; \
+    const f2_t tt_ = f2_t{t_, t_}; \
     _Pragma("unroll") for (int g = 0; g < NG_; g++) { \
-      r[2 * g] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].x, rk_[g].y}, r[2 * g]); \
-      r[2 * g + 1] = __builtin_elementwise_fma(nt_, f2_t{rk_[g].z, rk_[g].w}, r[2 * g + 1]); } \
+      pk_fnma(r[2 * g], tt_, f2_t{rk_[g].x, rk_[g].y}); \
+      pk_fnma(r[2 * g + 1], tt_, f2_t{rk_[g].z, rk_[g].w}); } \
     diag = fmaf(-t_, tk_, diag); } while (0)
 #define L_ROUNDS(NG_) do { \
     int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2; \
@@ -589,12 +595,12 @@ __device__ __forceinline__ void ldl_factor2(float* HM, float* HR, float* DVM, fl
     float4 km_[NG_], kh_[NG_]; \
     _Pragma("unroll") for (int g = 0; g < NG_; g++) { km_[g] = *(const float4*)(HM + (p_) * RS + 4 * g); kh_[g] = *(const float4*)(HR + (p_) * RS + 4 * g); } \
     const float tm_ = mask_select(tkm_ * dkm_, am_), th_ = mask_select(tkh_ * dkh_, am_); \
-    const f2_t ntm_ = f2_t{-tm_, -tm_}, nth_ = f2_t{-th_, -th_}; \
+    const f2_t ttm_ = f2_t{tm_, tm_}, tth_ = f2_t{th_, th_}; \
     _Pragma("unroll") for (int g = 0; g < NG_; g++) { \
-      rm[2 * g] = __builtin_elementwise_fma(ntm_, f2_t{km_[g].x, km_[g].y}, rm[2 * g]); \
-      rm[2 * g + 1] = __builtin_elementwise_fma(ntm_, f2_t{km_[g].z, km_[g].w}, rm[2 * g + 1]); \
-      rh[2 * g] = __builtin_elementwise_fma(nth_, f2_t{kh_[g].x, kh_[g].y}, rh[2 * g]); \
-      rh[2 * g + 1] = __builtin_elementwise_fma(nth_, f2_t{kh_[g].z, kh_[g].w}, rh[2 * g + 1]); } \
+      pk_fnma(rm[2 * g], ttm_, f2_t{km_[g].x, km_[g].y}); \
+      pk_fnma(rm[2 * g + 1], ttm_, f2_t{km_[g].z, km_[g].w}); \
+      pk_fnma(rh[2 * g], tth_, f2_t{kh_[g].x, kh_[g].y}); \
+      pk_fnma(rh[2 * g + 1], tth_, f2_t{kh_[g].z, kh_[g].w}); } \
     dgm = fmaf(-tm_, tkm_, dgm); dgh = fmaf(-th_, tkh_, dgh); \
     x = fmaf(-tm_, bcast(x, p_), x); } while (0)
 #define ROUND_BODY2(NG_) do { \
@@ -609,24 +615,28 @@ __device__ __forceinline__ void ldl_factor2(float* HM, float* HR, float* DVM, fl
     if (p1 >= 0) { APPLY_PIVOT2(NG_, p1, a1); APPLY_PIVOT2(NG_, p2, a2); } \
     WSYNC(); } while (0)
   {
+    // Rounds come deepest level first, so the group count never grows from one round to the next: one loop per group count,
+    // run one after the other (a switch inside one loop makes every join copy the whole register rows).
     int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2, dep = RND[0].depth;
     unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
-#pragma unroll 1
-    for (int rd = 0; rd < nround; rd++) {
-      const int rn = rd + 1 < nround ? rd + 1 : rd;
-      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2, ndep = RND[rn].depth;
-      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2];
-      const int ng = (dep + 3) >> 2;
-      if (ng <= 1) ROUND_BODY2(1);
-      else if (MAXD >= 8 && ng == 2) ROUND_BODY2((MAXD >= 8 ? 2 : 1));
-      else if (MAXD >= 12 && ng == 3) ROUND_BODY2((MAXD >= 12 ? 3 : 1));
-      else if (MAXD >= 16 && ng == 4) ROUND_BODY2((MAXD >= 16 ? 4 : 1));
-      else if (MAXD >= 20 && ng == 5) ROUND_BODY2((MAXD >= 20 ? 5 : 1));
-      else if (MAXD >= 24 && ng == 6) ROUND_BODY2((MAXD >= 24 ? 6 : 1));
-      else if (MAXD >= 28 && ng == 7) ROUND_BODY2((MAXD >= 28 ? 7 : 1));
-      else ROUND_BODY2(MAXD / 4);
-      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; dep = ndep;
+    int rd = 0;
+#define ROUNDS_AT(NG_, COND_) \
+    _Pragma("unroll 1") while (rd < nround && (COND_)) { \
+      const int rn = rd + 1 < nround ? rd + 1 : rd; \
+      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2, ndep = RND[rn].depth; \
+      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2]; \
+      ROUND_BODY2(NG_); \
+      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; dep = ndep; rd++; \
     }
+    if (MAXD >= 32) ROUNDS_AT((MAXD >= 32 ? 8 : 1), dep > 28)
+    if (MAXD >= 28) ROUNDS_AT((MAXD >= 28 ? 7 : 1), dep > 24)
+    if (MAXD >= 24) ROUNDS_AT((MAXD >= 24 ? 6 : 1), dep > 20)
+    if (MAXD >= 20) ROUNDS_AT((MAXD >= 20 ? 5 : 1), dep > 16)
+    if (MAXD >= 16) ROUNDS_AT((MAXD >= 16 ? 4 : 1), dep > 12)
+    if (MAXD >= 12) ROUNDS_AT((MAXD >= 12 ? 3 : 1), dep > 8)
+    if (MAXD >= 8) ROUNDS_AT((MAXD >= 8 ? 2 : 1), dep > 4)
+    ROUNDS_AT(1, true)
+#undef ROUNDS_AT
   }
 #undef ROUND_BODY2
 #undef APPLY_PIVOT2
