@@ -206,10 +206,18 @@ __device__ __forceinline__ v3 qrot(q4 q, v3 v) {
   v3 t = scl3(cross(qv, v), 2.0f);
   return add3(add3(v, scl3(t, q.w)), cross(qv, t));
 }
+// 1 / sqrt(x): v_rsq_f32 (1 ulp) + one Newton step, ~6 VALU; the IEEE sqrt and divide sequences cost ~35
+__device__ __forceinline__ float rsqrt_nr(float x) { const float r = __builtin_amdgcn_rsqf(x); return r * fmaf(-0.5f * x * r, r, 1.5f); }
+// 1 / x in double from the fp32 reciprocal and two Newton steps (the IEEE fp64 divide is ~20 instructions)
+__device__ __forceinline__ double rcp_f64_nr(double x) {
+  double r = (double)__builtin_amdgcn_rcpf((float)x);
+  r = r * (2.0 - x * r);
+  return r * (2.0 - x * r);
+}
 __device__ __forceinline__ q4 qnormalize(q4 q) {
   float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
   if (n2 < 1e-30f) { q4 r = {1.f, 0.f, 0.f, 0.f}; return r; }
-  float inv = 1.0f / sqrtf(n2);
+  const float inv = rsqrt_nr(n2);
   q4 r = {q.w * inv, q.x * inv, q.y * inv, q.z * inv};
   return r;
 }
@@ -474,8 +482,11 @@ __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, 
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ double dpp_f64(double v) {
   const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, false);
-  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, false);
+  // full row mask: lanes without a source read 0 through bound_ctrl and the destination needs no initialisation (2 v_mov per
+  // step saved); a partial row mask keeps `old` = 0 in the rows it leaves out
+  constexpr bool BC = ROWMASK == 0xF;
+  const int lo2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROWMASK, 0xF, BC);
+  const int hi2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROWMASK, 0xF, BC);
   return __hiloint2double(hi2, lo2);
 }
 __device__ __forceinline__ double wave_prefix_f64(double v) {
@@ -1203,9 +1214,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       const int last = isb ? lane + BTABI(blo, 8).y - 1 : lane;
       const double dm = (double)mass;
       const double dx = (double)xi.x - (double)com.x, dy = (double)xi.y - (double)com.y, dz = (double)xi.z - (double)com.z;
-      const double ms = subtree_sum_f64(dm, last);
+      const double ms = (double)BTAB(blo, 2).w;                              // subtree mass: a model constant
       const double px = subtree_sum_f64(dm * dx, last), py = subtree_sum_f64(dm * dy, last), pz = subtree_sum_f64(dm * dz, last);
-      const double minv = ms > 0.0 ? 1.0 / ms : 0.0;
+      const double minv = ms > 0.0 ? rcp_f64_nr(ms) : 0.0;
       const double ex = px * minv, ey = py * minv, ez = pz * minv;           // subtree CoM relative to the tree CoM
       // one scan at a time: pinf() (asm volatile) fences keep the compiler from forming all sixteen fp64 inputs
       // up front, which would cost ~50 VGPRs; each result is converted to fp32 at once
@@ -1613,10 +1624,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     if (jtype == FMJ_JNT_FREE && A.integrate && !frozen) {     // free joint position update (lane = root body)
       QP[qadr] += M.h * QV[dadr]; QP[qadr + 1] += M.h * QV[dadr + 1]; QP[qadr + 2] += M.h * QV[dadr + 2];
       const v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
-      const float n = sqrtf(dot3(w, w));
+      const float n2 = dot3(w, w), rn = rsqrt_nr(n2), n = n2 * rn;
       q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
       qo = qnormalize(qo);
-      if (n >= 1e-15f) qo = qmul(qo, axisangle_small(scl3(w, 1.0f / n), M.h * n));
+      if (n2 >= 1e-30f) qo = qmul(qo, axisangle_small(scl3(w, rn), M.h * n));
       QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
       if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
     }
