@@ -744,6 +744,7 @@ __device__ __forceinline__ float impedance(float d0, float d1, float width, floa
   if (x >= 1.f) y = 1.f;
   else if (x <= 0.f) y = 0.f;
   else if (power == 1.f) y = x;
+  else if (power == 2.f) y = x <= mid ? x * x / mid : 1.f - (1.f - x) * (1.f - x) / (1.f - mid);   // MuJoCo's default solimp: no powf (~300 VALU a pair)
   else if (x <= mid) y = powf(x, power) / powf(mid, power - 1.f);
   else y = 1.f - powf(1.f - x, power) / powf(1.f - mid, power - 1.f);
   return d0 + y * (d1 - d0);
