@@ -1041,6 +1041,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const float4 c_axis_q0 = BTAB(blo, 5);
     const float4 c_jpos_k = BTAB(blo, 6);
     // ---- K: local transforms, composed along the chains by pointer jumping (log2(depth) rounds)
+    const bool any_jpos = M.any_jpos != 0, any_bquat = M.any_bquat != 0, any_iquat = M.any_iquat != 0;   // model-wide (uniform) shortcuts
     v3 xp; q4 xq;
     {
       const float4 c_pos_mass = BTAB(blo, 0);
@@ -1053,10 +1054,13 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         xq = qnormalize(rq);
       } else if (jtype == FMJ_JNT_HINGE) {
         const float q = QP[qadr] - c_axis_q0.w;
-        const v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), jp = mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z);
-        const q4 ql = axisangle(ax, q);
-        xp = add3(xp, qrot(xq, sub3(jp, qrot(ql, jp))));
-        xq = qmul(xq, ql);
+        const v3 ax = mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z);
+        const q4 ql = axisangle_mid(ax, q);       // half-angle sin / cos by polynomial for |q| <= pi
+        if (any_jpos) {                           // anchor off the body origin: the body turns about the anchor
+          const v3 jp = mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z);
+          xp = add3(xp, qrot(xq, sub3(jp, qrot(ql, jp))));
+        }
+        xq = any_bquat ? qmul(xq, ql) : ql;       // body frames aligned with their parents': the local rotation is the joint's
       } else if (jtype == FMJ_JNT_SLIDE) {
         const float q = QP[qadr] - c_axis_q0.w;
         xp = add3(xp, qrot(xq, scl3(mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z), q)));
@@ -1089,15 +1093,15 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     // ---- C: tree CoM (wave reduction, result is wave-uniform), cinert, cdof
     const float mass = isb ? BTAB(blo, 0).w : 0.f;
     v3 com;
-    com.x = bcast(wave_sum(mass * xi.x), 0) * M.mtot_inv;
-    com.y = bcast(wave_sum(mass * xi.y), 0) * M.mtot_inv;
-    com.z = bcast(wave_sum(mass * xi.z), 0) * M.mtot_inv;
+    com.x = wave_sum_fast(mass * xi.x) * M.mtot_inv;     // DPP reductions, no LDS traffic
+    com.y = wave_sum_fast(mass * xi.y) * M.mtot_inv;
+    com.z = wave_sum_fast(mass * xi.z) * M.mtot_inv;
     float iw[6];     // world-frame inertia about the body's own CoM
     {
       const float4 c_iquat = BTAB(blo, 3);
       const float4 c_inertia = BTAB(blo, 4);
       q4 iq = {c_iquat.x, c_iquat.y, c_iquat.z, c_iquat.w};
-      const m33 Ri = q2m(qmul(xq, iq));
+      const m33 Ri = q2m(any_iquat ? qmul(xq, iq) : xq);
       const float i0 = c_inertia.x, i1 = c_inertia.y, i2 = c_inertia.z;
       iw[0] = Ri.a[0] * Ri.a[0] * i0 + Ri.a[1] * Ri.a[1] * i1 + Ri.a[2] * Ri.a[2] * i2;
       iw[1] = Ri.a[3] * Ri.a[3] * i0 + Ri.a[4] * Ri.a[4] * i1 + Ri.a[5] * Ri.a[5] * i2;
@@ -1120,7 +1124,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
         const v3 axw = qrot(xq, mk3(c_axis_q0.x, c_axis_q0.y, c_axis_q0.z));
         s6 cd;
         if (jtype == FMJ_JNT_HINGE) {
-          const v3 anchor = add3(xp, qrot(xq, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z)));
+          const v3 anchor = any_jpos ? add3(xp, qrot(xq, mk3(c_jpos_k.x, c_jpos_k.y, c_jpos_k.z))) : xp;
           cd.r = axw; cd.l = cross(axw, sub3(com, anchor));
         } else { cd.r = mk3(0.f, 0.f, 0.f); cd.l = axw; }
         lds_put6(CD + dadr * 8, cd);
