@@ -83,7 +83,7 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
     return sim, m, (qpos, qvel, psi)
 
 
-def cpu_baseline(m, sim, target_seconds=15.0):
+def cpu_baseline(m, sim, target_seconds=12.0):
     """The fp64 CPU oracle (C restatement, NOT MuJoCo: the reference's mj_step loop cannot run here, see
     BASELINE.md §2) timed on this box's host cores on a bounded sample of the same workload."""
     import subprocess
@@ -112,12 +112,12 @@ def cpu_baseline(m, sim, target_seconds=15.0):
     water = dict(surface=h.water._surface, velocity=h.water._velocity, viscosity=h.water._viscosity, gravity=-9.81,
                  use_buoyancy=h.buoyancy)
     t0 = time.perf_counter()
-    oracle.run_fused(m, st, 20, swim=h.swim_dict(), water=water, buffer_size=20, controller=1, wave=wave, n_threads=cores)
-    rate = n_envs*20/(time.perf_counter() - t0)                                # calibration pass
-    n_steps = int(max(50, min(5000, target_seconds*rate/n_envs)))
+    oracle.run_fused(m, st, 300, swim=h.swim_dict(), water=water, buffer_size=100, controller=1, wave=wave, n_threads=cores)
+    rate = n_envs*300/(time.perf_counter() - t0)                               # calibration pass
+    n_steps = int(max(50, min(20000, target_seconds*rate/n_envs)))
     t0 = time.perf_counter()
-    oracle.run_fused(m, st, n_steps, swim=h.swim_dict(), water=water, buffer_size=n_steps, controller=1, wave=wave,
-                     n_threads=cores)
+    oracle.run_fused(m, st, n_steps, swim=h.swim_dict(), water=water, buffer_size=100, controller=1, wave=wave,
+                     n_threads=cores)                                          # rows go to a 100-row ring, like the GPU run
     dt = time.perf_counter() - t0
     return dict(value=n_envs*n_steps/dt, unit='env-steps/s', cores=cores, kind='port',
                 sample=f'{n_envs} envs x {n_steps} steps of the same salamander-33 swim workload, fp64 C oracle '
