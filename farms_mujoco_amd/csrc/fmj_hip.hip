@@ -214,6 +214,15 @@ __device__ __forceinline__ double rcp_f64_nr(double x) {
   r = r * (2.0 - x * r);
   return r * (2.0 - x * r);
 }
+// sin(2 pi t), t in revolutions: exact reduction to [-1/2, 1/2] (v_rndne), fold to [0, 1/4], odd polynomial of degree 11 on
+// [0, pi/2] (truncation 6e-8): ~15 VALU against ~45 for the library sinf with its radian argument reduction
+__device__ __forceinline__ float sin_turns(float t) {
+  t -= rintf(t);
+  const float a = fabsf(t);
+  const float x = 6.2831853071795865f * (a > 0.25f ? 0.5f - a : a), x2 = x * x;
+  const float s = x * fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, fmaf(x2, -1.0f / 39916800.0f, 1.0f / 362880.0f), -1.0f / 5040.0f), 1.0f / 120.0f), -1.0f / 6.0f), 1.0f);
+  return copysignf(s, t);
+}
 __device__ __forceinline__ q4 qnormalize(q4 q) {
   float n2 = q.w * q.w + q.x * q.x + q.y * q.y + q.z * q.z;
   if (n2 < 1e-30f) { q4 r = {1.f, 0.f, 0.f, 0.f}; return r; }
