@@ -156,7 +156,7 @@ def other_workloads(n_envs, chunk, device):
         res[name] = {'value': n_envs*(steps//chunk)*chunk/dt, 'unit': 'env-steps/s', 'warmup': warm, 'steps': (steps//chunk)*chunk,
                      'launch_ms': {'min': float(ms.min()), 'median': float(np.median(ms)), 'max': float(ms.max())},
                      'config': 'BASELINE configs[3]: salamander-33 walking on a plane' if name == 'walk' else
-                               'BASELINE configs[4]: half eels, half centipedes, one bucket (launch) per morphology'}
+                               'BASELINE configs[4]: half eels, half centipedes, one bucket (launch, HIP stream) per morphology, side by side'}
         del sims, batch
     return res
 
@@ -226,7 +226,7 @@ def main():
         sims = [sim]
 
     from farms_mujoco_amd.simulation.buckets import BucketedSimulation
-    batch = BucketedSimulation(sims)
+    batch = BucketedSimulation(sims, overlap=os.environ.get('FMJ_BUCKET_OVERLAP', '1') == '1')
 
     def run(n):
         """n steps in launches of `chunk` (the last one shorter), a HIP event pair on the launch stream around each."""
@@ -235,7 +235,7 @@ def main():
             c = min(chunk, n - done)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            batch.step_fused(c)               # mixed: one launch per morphology bucket
+            batch.step_fused(c)               # mixed: one launch per morphology bucket, side by side on their own streams
             e1.record()
             evs.append((e0, e1, c))
             done += c
@@ -300,7 +300,7 @@ def main():
                                     'walk': f'BASELINE configs[3]: {n_envs}x salamander-33 walking on a plane per GPU, joint limits + '
                                             f'sphere/capsule contacts, pyramidal cone, PGS <= 50 sweeps, link/joint/contact rows logged',
                                     'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
-                                             f'GPU, one bucket per morphology'}[args.workload],
+                                             f'GPU, one bucket (launch, HIP stream) per morphology, launched side by side'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',
                        'lds_bytes_per_env': info['lds_bytes_per_env']},
             'launch_ms': {'n': int(full.size), 'min': float(full.min()*1e3), 'median': float(np.median(full)*1e3), 'max': float(full.max()*1e3)},

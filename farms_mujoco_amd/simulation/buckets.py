@@ -1,13 +1,14 @@
 """Mixed-morphology batches (BASELINE configs[4]): one :class:`Simulation` per morphology ("bucket"), no padding.
 
 Every bucket is its own launch of the fused step kernel, with its own workgroup shape and LDS footprint; the buckets
-exchange nothing (independent environments), so there is no collective.  By default the launches follow each other on the
-caller's stream.  ``overlap=True`` forks the caller's stream into one HIP stream per bucket, launches the buckets side by
-side and joins them again (stream semantics for the caller unchanged: work queued before ``step_fused`` is visible to
-every bucket, work queued after it sees every bucket's result).  Measured on MI355X with 2048 eels + 2048 centipedes
-(round 2): 6.10 ms per 100 steps side by side against 5.60 ms back to back - the centipede workgroups take the whole LDS of a
-CU (8 x 19 KB), so the eel workgroups only trickle in next to them and two large kernels share the instruction caches -
-hence the default.
+exchange nothing (independent environments), so there is no collective.  Launched one after the other on one stream, a
+small bucket leaves most of the chip idle while it runs (2048 eels are 1024 wavefronts on 1024 SIMDs: one per SIMD,
+pure latency).  ``overlap=True`` (the default) forks the caller's stream into one HIP stream per bucket, launches the
+buckets side by side and joins them again, so that the workgroups of all buckets share the CUs.  Stream semantics for
+the caller are unchanged: work queued before ``step_fused`` is visible to every bucket, work queued after it sees every
+bucket's result.  Measured on MI355X with 2048 eels + 2048 centipedes (round 2): 3.73 ms per 100 steps side by side
+against 4.97 ms back to back (109 M against 82 M env-steps/s).  (It only pays since the centipede's workgroups stopped
+taking a CU's whole LDS: at 19 KB each, 8 of them left room for one eel workgroup per CU and side by side was slower.)
 """
 import torch
 
@@ -15,7 +16,7 @@ import torch
 class BucketedSimulation:
     """Drives several fused simulations (one per morphology) as one batch."""
 
-    def __init__(self, simulations, overlap: bool = False):
+    def __init__(self, simulations, overlap: bool = True):
         self.simulations = list(simulations)
         self.overlap = bool(overlap)
         assert self.simulations, 'at least one bucket'
