@@ -97,7 +97,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 2         # FMJ_ABI_VERSION of include/fmj.h
+ABI_VERSION = 3         # FMJ_ABI_VERSION of include/fmj.h
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:

@@ -74,6 +74,8 @@ struct DevModel {
   const float4* ptab;         // [nplane][PT_STRIDE]
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
   const float* hf_data;       // [hf_nrow][hf_ncol] heightfield samples (one heightfield per model)
+  const float4* mesh_vert;    // [nmeshvert] hull vertices of the mesh geoms, geom frame (gtab size.x / .y: first vertex, count)
+  int any_mesh;
   int hf_nrow, hf_ncol;
   int npair, nfl;             // explicit geom pairs; fork rows (4 per pair contact) the LDS path provides
   const float4* qtab;         // [npair][QT_STRIDE]: (geom1, geom2 bits, friction, -), (solref, solimp 0..1), (solimp 2..4, -)
@@ -898,8 +900,9 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 #define STAMP(i)
 #endif
 
-// PAIRS: the model has explicit geom pairs (rows over two branches of the tree); a separate instantiation because the
-// fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills.
+// PAIRS: the model has explicit geom pairs (rows over two branches of the tree) or mesh geoms; a separate instantiation
+// because the fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills (and the mesh
+// vertex loop another 20).
 template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
@@ -1494,6 +1497,40 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               for (int k = 0; k < 4; k++) nq[k] = nrm_;
             }
           }
+          if (PAIRS && M.any_mesh) {      // convex mesh: its deepest penetrating vertices, deepest first (include/fmj.h)
+            const int4 gi = g < M.ngeom ? GTABI(g, 0) : make_int4(-1, 0, 0, 0);
+            if (gi.x == FMJ_GEOM_MESH) {
+              const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
+              const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+              const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
+              const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+              mu = fmaxf(pp.x, gs.w);
+              v3 nc0;
+              if (ground_dist(M, pl, pn, pp, cen, &nc0) < gs.z) {       // the ground is within the bounding radius
+                const m33 R = q2m(qmul(bqq, gqq));
+                const int v0 = __float_as_int(gs.x), nvert = __float_as_int(gs.y);
+                for (int vtx = 0; vtx < nvert; vtx++) {
+                  const float4 vv = ldg4(M.mesh_vert, (unsigned)(v0 + vtx));
+                  v3 tc = add3(cen, mrot(R, mk3(vv.x, vv.y, vv.z))), tn;
+                  float td = ground_dist(M, pl, pn, pp, tc, &tn);
+                  if (td < 0.f) {
+                    bool have = true;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {                       // carry the displaced entry down; a filled empty slot ends the walk
+                      const bool empty = k >= cnt;
+                      if (have && (empty || td < dq[k])) {
+                        const float sd = dq[k]; const v3 sc = cq[k], sn = nq[k];
+                        dq[k] = td; cq[k] = tc; nq[k] = tn;
+                        td = sd; tc = sc; tn = sn;
+                        have = !empty;
+                      }
+                    }
+                    if (cnt < 4) cnt++;
+                  }
+                }
+              }
+            }
+          }
           int before = 0, total = 0;
 #pragma unroll
           for (int k = 0; k < 4; k++) { const unsigned long long bk = __ballot(cnt > k); before += __popcll(bk & lt); total += __popcll(bk); }
@@ -1836,7 +1873,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   }
   return (step_kernel_t)k;
 }
-static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons ? (c->dm.npair > 0 ? 2 : 1) : 0, 0); }
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons ? ((c->dm.npair > 0 || c->dm.any_mesh) ? 2 : 1) : 0, 0); }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
     step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 3 ? 3 : 2);
@@ -1892,7 +1929,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
   const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
   if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
-  int any_limit = 0, nplane = 0, any_box = 0, n_hfield = 0;     // nplane counts the ground geoms: planes and the heightfield
+  int any_limit = 0, nplane = 0, any_box = 0, n_hfield = 0, any_mesh = 0;     // nplane counts the ground geoms: planes and the heightfield
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE) any_limit = 1;
   for (int g = 0; g < m->ngeom; g++) {
     int t = m->geom_type[g];
@@ -1904,7 +1941,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
         return set_err(FMJ_ERR_ARG, "fmj_create: heightfield needs nrow, ncol >= 2, data and positive x / y radii");
       nplane++;
     }
-    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX && t != FMJ_GEOM_CYLINDER) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / heightfield / sphere / capsule / cylinder / box geoms are in the HIP path");
+    else if (t == FMJ_GEOM_MESH) {
+      if (m->nmeshvert < 1 || !m->mesh_vert || !m->geom_vertadr || !m->geom_vertnum) return set_err(FMJ_ERR_ARG, "fmj_create: mesh geom without mesh_vert / geom_vertadr / geom_vertnum");
+      if (m->geom_vertnum[g] < 1 || m->geom_vertadr[g] < 0 || m->geom_vertadr[g] + m->geom_vertnum[g] > m->nmeshvert)
+        return set_err(FMJ_ERR_ARG, "fmj_create: mesh vertex range out of bounds");
+      if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
+      any_mesh = 1;
+    }
+    else if (t != FMJ_GEOM_SPHERE && t != FMJ_GEOM_CAPSULE && t != FMJ_GEOM_BOX && t != FMJ_GEOM_CYLINDER) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: only plane / heightfield / sphere / capsule / cylinder / box / convex mesh geoms are in the HIP path");
     else if (m->geom_bodyid[g] < 1 || m->geom_bodyid[g] >= nb) return set_err(FMJ_ERR_ARG, "fmj_create: geom_bodyid out of range");
     if (t == FMJ_GEOM_BOX || t == FMJ_GEOM_CYLINDER) any_box = 1;      // geoms with up to 4 contacts
   }
@@ -2114,6 +2158,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       for (int a = b; a >= 1 && last < 0; a = m->body_parentid[a]) if (m->body_dofnum[a] > 0) last = m->body_dofadr[a] + m->body_dofnum[a] - 1;
       g_info[g] = make_int4(m->geom_type[g], b, last, 0);
       g_size[g] = f4(m->geom_size[3 * g], m->geom_size[3 * g + 1], m->geom_size[3 * g + 2], m->geom_friction[3 * g]);
+      if (m->geom_type[g] == FMJ_GEOM_MESH) {          // first vertex, vertex count, bounding radius about the geom origin
+        double r2 = 0;
+        for (int i = m->geom_vertadr[g]; i < m->geom_vertadr[g] + m->geom_vertnum[g]; i++) {
+          const double* v = m->mesh_vert + 3 * (size_t)i;
+          r2 = fmax(r2, v[0] * v[0] + v[1] * v[1] + v[2] * v[2]);
+        }
+        g_size[g] = make_float4(ibits(m->geom_vertadr[g]), ibits(m->geom_vertnum[g]), (float)(sqrt(r2) * (1.0 + 1e-6)), (float)m->geom_friction[3 * g]);
+      }
       g_pos[g] = f4(m->geom_pos[3 * g], m->geom_pos[3 * g + 1], m->geom_pos[3 * g + 2], m->body_invweight0[2 * b]);
       g_quat[g] = f4(m->geom_quat[4 * g], m->geom_quat[4 * g + 1], m->geom_quat[4 * g + 2], m->geom_quat[4 * g + 3]);
       g_sol0[g] = f4(m->geom_solref[2 * g], m->geom_solref[2 * g + 1], m->geom_solimp[5 * g], m->geom_solimp[5 * g + 1]);
@@ -2172,6 +2224,12 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       qtab[p * QT_STRIDE + 2] = f4(m->pair_solimp[5 * p + 2], m->pair_solimp[5 * p + 3], m->pair_solimp[5 * p + 4], 0);
     }
     UP(qtab, qtab);
+  }
+  D.any_mesh = cons ? any_mesh : 0; D.mesh_vert = nullptr;
+  if (any_mesh) {
+    std::vector<float4> mv((size_t)m->nmeshvert);
+    for (int i = 0; i < m->nmeshvert; i++) mv[i] = f4(m->mesh_vert[3 * i], m->mesh_vert[3 * i + 1], m->mesh_vert[3 * i + 2], 0);
+    UP(mv, mesh_vert);
   }
   D.hf_nrow = D.hf_ncol = 0; D.hf_data = nullptr;
   if (n_hfield) {

@@ -23,7 +23,7 @@ def _floats(text, n=None, default=None):
 class Geometry:
     kind: str                       # 'sphere' | 'capsule' | 'cylinder' | 'box' | 'plane' | 'heightmap' | 'mesh'
     size: np.ndarray                # sphere: [r]; capsule/cylinder: [r, length]; box: [x, y, z]; plane: normal; heightmap: [x, y, z] extents
-    uri: str = ''                   # heightmap: image file, relative to the SDF's directory
+    uri: str = ''                   # heightmap: image file; mesh: .obj / .stl file (size = its <scale>); relative to the SDF's directory
 
     def bounding_radius(self) -> float:
         """MuJoCo geom_rbound of the shape (used for SwimmingHandler heights, reference drag.pyx:364-372)."""
@@ -125,8 +125,10 @@ class ModelSDF:
                         geo = Geometry(kind, _floats(n.text if n is not None else '0 0 1', 3))
                     elif kind == 'heightmap':
                         geo = Geometry(kind, _floats(k.find('size').text, 3), uri=k.find('uri').text.strip())
-                    else:
-                        geo = Geometry(kind, np.zeros(3))
+                    else:                               # mesh: <uri>, optional <scale>
+                        sc = k.find('scale')
+                        geo = Geometry(kind, _floats(sc.text if sc is not None else '1 1 1', 3),
+                                       uri=k.find('uri').text.strip() if k.find('uri') is not None else '')
                 cols.append(Collision(ce.get('name', f'{le.get("name")}_collision'), pose_of(ce), geo))
             links.append(Link(le.get('name'), pose_of(le), inertial, cols))
         joints = []

@@ -21,8 +21,8 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
-GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX = 0, 1, 2, 3, 5, 6
-ABI_VERSION = 2
+GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 5, 6, 7
+ABI_VERSION = 3
 
 DEFAULT_SOLREF = (0.02, 1.0)
 DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
@@ -181,6 +181,24 @@ class ModelBuilder:
                             friction=np.asarray(friction, float), solref=np.asarray(solref, float),
                             solimp=np.asarray(solimp, float)))
 
+    def add_mesh_geom(self, body, vertices, pos=(0, 0, 0), quat=(1, 0, 0, 0), friction=(0, 0, 0), solref=DEFAULT_SOLREF,
+                      solimp=DEFAULT_SOLIMP, hull=True):
+        """Convex mesh collision geom (reference mjcf.py:270-413: every SDF mesh collision becomes a MuJoCo mesh geom,
+        which collides as its convex hull).  ``vertices`` [n, 3] in the geom frame; with ``hull`` they are reduced to the
+        vertices of their convex hull (scipy), in their original order."""
+        v = np.ascontiguousarray(vertices, float).reshape(-1, 3)
+        assert len(v) >= 1, 'a mesh needs vertices'
+        if hull and len(v) > 4:
+            try:
+                from scipy.spatial import ConvexHull
+                v = v[np.sort(ConvexHull(v).vertices)]
+            except Exception:          # degenerate (flat / collinear) clouds keep every vertex
+                pass
+        self.add_geom(body, GEOM_MESH, (0, 0, float(np.linalg.norm(v, axis=1).max())), pos=pos, quat=quat, friction=friction,
+                      solref=solref, solimp=solimp)
+        b = self.bodies[body if isinstance(body, int) else self.body_id(body)]
+        b.geoms[-1]['vertices'] = v
+
     def add_hfield(self, data, size, pos=(0, 0, 0), quat=(1, 0, 0, 0), friction=(0, 0, 0), solref=DEFAULT_SOLREF,
                    solimp=DEFAULT_SOLIMP):
         """World-attached heightfield (reference mjcf.py:486-522): ``data`` [nrow, ncol] with rows along +y and columns
@@ -244,6 +262,7 @@ _CMODEL_FIELDS = (
         [(n, _D) for n in ('geom_size', 'geom_pos', 'geom_quat', 'geom_friction', 'geom_solref', 'geom_solimp',
                            'body_invweight0')] +
         [('hfield_nrow', ctypes.c_int32), ('hfield_ncol', ctypes.c_int32), ('hfield_size', ctypes.c_double*4), ('hfield_data', _D)] +
+        [('nmeshvert', ctypes.c_int32), ('mesh_vert', _D), ('geom_vertadr', _I), ('geom_vertnum', _I)] +
         [('npair', ctypes.c_int32), ('pair_geom1', _I), ('pair_geom2', _I), ('pair_friction', _D), ('pair_solref', _D), ('pair_solimp', _D)] +
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
          ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)]
@@ -258,12 +277,13 @@ class _CModel(ctypes.Structure):
 _INT_FIELDS = ('body_parentid', 'body_rootid', 'body_jntadr', 'body_dofadr', 'body_dofnum', 'jnt_type',
                'jnt_qposadr', 'jnt_dofadr', 'jnt_bodyid', 'jnt_limited', 'dof_bodyid', 'dof_jntid',
                'dof_parentid', 'dof_Madr', 'actuator_jntid', 'actuator_ctrllimited', 'actuator_forcelimited',
-               'geom_type', 'geom_bodyid', 'pair_geom1', 'pair_geom2')
+               'geom_type', 'geom_bodyid', 'pair_geom1', 'pair_geom2', 'geom_vertadr', 'geom_vertnum')
 _DBL_FIELDS = ('body_pos', 'body_quat', 'body_ipos', 'body_iquat', 'body_mass', 'body_inertia', 'jnt_pos',
                'jnt_axis', 'jnt_stiffness', 'jnt_range', 'jnt_solref', 'jnt_solimp', 'jnt_margin', 'qpos0',
                'dof_armature', 'dof_damping', 'dof_invweight0', 'actuator_gain', 'actuator_bias',
                'actuator_ctrlrange', 'actuator_forcerange', 'geom_size', 'geom_pos', 'geom_quat',
-               'geom_friction', 'geom_solref', 'geom_solimp', 'body_invweight0', 'pair_friction', 'pair_solref', 'pair_solimp')
+               'geom_friction', 'geom_solref', 'geom_solimp', 'body_invweight0', 'pair_friction', 'pair_solref', 'pair_solimp',
+               'mesh_vert')
 
 
 class Model:
@@ -417,6 +437,15 @@ class Model:
         m.geom_friction = np.array([g['friction'] for _, g in geoms], float).reshape(-1, 3)
         m.geom_solref = np.array([g['solref'] for _, g in geoms], float).reshape(-1, 2)
         m.geom_solimp = np.array([g['solimp'] for _, g in geoms], float).reshape(-1, 5)
+        # convex meshes: the vertices of all mesh geoms, concatenated in geom order
+        m.geom_vertadr = np.full(m.ngeom, -1, np.int32); m.geom_vertnum = np.zeros(m.ngeom, np.int32)
+        verts = []
+        for gi, (_, g) in enumerate(geoms):
+            if g['type'] == GEOM_MESH:
+                m.geom_vertadr[gi] = sum(len(v) for v in verts); m.geom_vertnum[gi] = len(g['vertices'])
+                verts.append(g['vertices'])
+        m.mesh_vert = np.concatenate(verts) if verts else np.zeros((0, 3))
+        m.nmeshvert = len(m.mesh_vert)
         # explicit geom pairs: every geom of body1 x every geom of body2, in the order the pairs were added
         pg1, pg2, pfr, psr, psi = [], [], [], [], []
         for pr in b.pairs:
@@ -505,6 +534,7 @@ class Model:
         for n in ('nbody', 'njnt', 'nq', 'nv', 'nu', 'ngeom', 'nM', 'solver_iterations', 'max_contacts'):
             setattr(c, n, int(getattr(self, n)))
         c.npair = int(getattr(self, 'npair', 0))
+        c.nmeshvert = int(getattr(self, 'nmeshvert', 0))
         c.timestep = self.timestep
         c.gravity = (ctypes.c_double*3)(*self.gravity)
         c.impratio = self.impratio

@@ -7,6 +7,8 @@ Counterpart of reference farms_mujoco/simulation/mjcf.py (``sdf2mjcf`` :647-1035
 (visuals, meshes, textures, cameras, lights) and muscles are out of scope."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from ..io.sdf import ModelSDF, Link
@@ -148,7 +150,20 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
             jkw.update(stiffness=stiffness, damping=damping)
         b.add_body(link.name, parent_name, **kw, **jkw)
         lo = link_opts.get(link.name)
-        rbound = link.collisions[0].geometry.bounding_radius() if link.collisions else 0.0
+        mesh_verts = {}                                     # collision index -> vertices of its mesh file (link units)
+
+        def mesh_of(ci):
+            if ci not in mesh_verts:
+                from ..io.mesh import read_vertices
+                g_ = link.collisions[ci].geometry
+                uri = g_.uri[len('file://'):] if g_.uri.startswith('file://') else g_.uri
+                mesh_verts[ci] = read_vertices(os.path.join(sdf.directory, os.path.expandvars(uri)), scale=g_.size[:3])
+            return mesh_verts[ci]
+        rbound = 0.0
+        if link.collisions:
+            g0 = link.collisions[0].geometry
+            # a mesh: half the diagonal of its bounding box (MuJoCo's geom_rbound of a mesh is taken about the mesh centre)
+            rbound = (0.5*float(np.linalg.norm(np.ptp(mesh_of(0), axis=0))) if g0.kind == 'mesh' else g0.bounding_radius())
         if lo is not None and getattr(lo, 'swimming', False):
             height = getattr(lo, 'height', None)
             b.set_swimming(link.name, density=lo.density, drag_coefficients=lo.drag_coefficients,
@@ -168,9 +183,11 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                     b.add_geom(link.name, GEOM_CYLINDER, (g.size[0]*units.meters, 0.5*g.size[1]*units.meters), **gkw)
                 elif g.kind == 'box':                   # SDF box size = full edge lengths, MuJoCo box size = half extents
                     b.add_geom(link.name, GEOM_BOX, tuple(0.5*x*units.meters for x in g.size[:3]), **gkw)
+                elif g.kind == 'mesh':                  # :270-413: a MuJoCo mesh geom collides as its convex hull
+                    b.add_mesh_geom(link.name, mesh_of(link.collisions.index(col))*units.meters, **gkw)
                 else:
                     raise NotImplementedError(f'collision shape {g.kind!r} of link {link.name} is outside the HIP subset '
-                                              '(sphere / capsule / cylinder / box against planes)')
+                                              '(sphere / capsule / cylinder / box / convex mesh against planes and a heightfield)')
         for child in sdf.get_children(link):
             add_link(child, link, link.name, sdf.get_parent_joint(child))
 
@@ -306,11 +323,20 @@ def model2mjcf_xml(m: Model) -> str:
                     at.update(limited='true', range=v(m.jnt_range[j]), margin=repr(float(m.jnt_margin[j])),
                               solreflimit=v(m.jnt_solref[j]), solimplimit=v(m.jnt_solimp[j]))
                 ET.SubElement(e, 'joint', **at)
+    asset = None
     for g in range(m.ngeom):
         t = int(m.geom_type[g])
+        common = dict(pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]), friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]),
+                      solimp=v(m.geom_solimp[g]), condim='3', margin='0')
+        if t == 7:                                   # convex mesh: its hull vertices as an inline mesh asset
+            if asset is None:
+                asset = ET.Element('asset'); root.insert(list(root).index(world), asset)
+            a0, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
+            ET.SubElement(asset, 'mesh', name=f'mesh_{g}', vertex=v(np.asarray(m.mesh_vert[a0:a0 + n]).ravel()))
+            ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type='mesh', mesh=f'mesh_{g}', **common)
+            continue
         size = {GEOM_PLANE: [1, 1, 0.1], 1: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
-        ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]),
-                      friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]), solimp=v(m.geom_solimp[g]), condim='3', margin='0')
+        ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), **common)
     if m.nu:
         act = ET.SubElement(root, 'actuator')
         for a in range(m.nu):

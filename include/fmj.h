@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMJ_ABI_VERSION 2
+#define FMJ_ABI_VERSION 3
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -38,7 +38,7 @@ enum {
 
 /* ---- joint / geom enums (values follow MuJoCo's mjtJoint / mjtGeom) ---------------------- */
 enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, FMJ_JNT_HINGE = 3 };
-enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6 };   /* mjtGeom values */
+enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6, FMJ_GEOM_MESH = 7 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
  * reference simulation.py:157-161,176-179).  An env whose status carries one of the BAD* bits is FROZEN: from the
@@ -151,6 +151,15 @@ typedef struct fmj_model {
   int32_t hfield_nrow, hfield_ncol;
   double hfield_size[4];
   const double* hfield_data;    /* [nrow*ncol] or NULL */
+  /* convex meshes (mjModel.mesh_vert of the geom's mesh asset; the reference turns every SDF mesh collision into one,
+   * mjcf.py:270-413): geom g of type FMJ_GEOM_MESH owns vertices [geom_vertadr[g], + geom_vertnum[g]) of mesh_vert, in
+   * the geom frame; they stand for their convex hull.  Against the ground a mesh gives up to 4 contacts, at its deepest
+   * penetrating vertices (deepest first, equal depths in vertex order).  Not MuJoCo's mjc_PlaneConvex point selection
+   * (support point + tilted directions), which is not restated here; explicit pairs with a mesh are refused. */
+  int32_t nmeshvert;
+  const double* mesh_vert;      /* [nmeshvert,3] or NULL */
+  const int32_t* geom_vertadr;  /* [ngeom] (-1: not a mesh) or NULL when nmeshvert == 0 */
+  const int32_t* geom_vertnum;  /* [ngeom] */
   /* explicit contact pairs between animat geoms (MJCF contact/pair, condim 3; the reference emits one per pair of
    * collision shapes of every morphology.self_collisions link pair, friction 0: mjcf.py:1012-1033).  Supported shapes:
    * sphere and capsule; one contact per pair, at the closest points of the two segments.  A sliding friction below

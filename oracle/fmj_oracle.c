@@ -611,6 +611,37 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
         cnt++;
       }
     }
+  } else if (type == FMJ_GEOM_MESH) {
+    /* convex mesh (include/fmj.h): up to 4 contacts at the deepest penetrating vertices, deepest first, equal depths in
+     * vertex order; nothing when the ground under the geom's origin is farther than the bounding radius (size[2]) */
+    double dc = ground_dist(m, w, p, gpos, n);
+    if (dc < size[2]) {
+      int cnt = 0; double dq[4], cq[4][3], nq[4][3];
+      const double* V = m->mesh_vert + 3 * (size_t)m->geom_vertadr[g];
+      for (int vtx = 0; vtx < m->geom_vertnum[g]; vtx++) {
+        double c[3], nn[3];
+        for (int k = 0; k < 3; k++) c[k] = gpos[k] + gm[3 * k] * V[3 * vtx] + gm[3 * k + 1] * V[3 * vtx + 1] + gm[3 * k + 2] * V[3 * vtx + 2];
+        double td = ground_dist(m, w, p, c, nn);
+        if (!(td < 0)) continue;
+        int have = 1;
+        for (int k = 0; k < 4 && have; k++) {
+          int empty = k >= cnt;
+          if (empty || td < dq[k]) {            /* carry the displaced entry down; a filled empty slot ends the walk */
+            double sd = dq[k], sc[3], sn[3];
+            memcpy(sc, cq[k], sizeof sc); memcpy(sn, nq[k], sizeof sn);
+            dq[k] = td; memcpy(cq[k], c, sizeof sc); memcpy(nq[k], nn, sizeof sn);
+            td = sd; memcpy(c, sc, sizeof sc); memcpy(nn, sn, sizeof sn);
+            if (empty) have = 0;
+          }
+        }
+        if (cnt < 4) cnt++;
+      }
+      for (int k = 0; k < cnt; k++) {
+        double pos[3];
+        for (int j = 0; j < 3; j++) pos[j] = cq[k][j] - nq[k][j] * 0.5 * dq[k];
+        add_contact(m, w, p, g, pos, nq[k], dq[k], mu, warn);
+      }
+    }
   }
 }
 

@@ -695,3 +695,121 @@ def test_self_collisions_with_ground_contacts_match_oracle(oracle):
     err = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
     print('self-collision + ground rollout: qpos abs err per env', err)
     assert err.max() < 5e-3 and np.median(err) < 1e-3
+
+
+def _mesh_walker(seed=5):
+    """A free trunk with a convex-mesh hull (random points on an ellipsoid) and two hinged limbs ending in small convex
+    meshes, above a plane: every ground contact comes from a mesh vertex."""
+    from farms_mujoco_amd.model import ModelBuilder, GEOM_PLANE
+    rng = np.random.default_rng(seed)
+
+    def cloud(n, a, b, c):
+        v = rng.normal(size=(n, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v*np.array([a, b, c])
+    b = ModelBuilder('meshbot', timestep=1e-3)
+    b.options['max_contacts'] = 16
+    b.add_body('trunk', pos=(0, 0, 0.06), mass=0.5, inertia=(2e-4, 6e-4, 7e-4), joint='free')
+    b.add_mesh_geom('trunk', cloud(60, 0.06, 0.03, 0.015), friction=(0.8, 0, 0))
+    for side, y in (('L', 0.04), ('R', -0.04)):
+        b.add_body(f'limb_{side}', parent='trunk', pos=(0.03, y, 0.0), mass=0.05, inertia=(2e-6, 8e-6, 8e-6),
+                   joint='hinge', axis=(0, 1, 0), damping=1e-3, limited=True, range=(-0.6, 0.6))
+        b.add_mesh_geom(f'limb_{side}', cloud(24, 0.03, 0.008, 0.008), pos=(0.03, 0, -0.02), quat=(0.9659258, 0, 0.258819, 0),
+                        friction=(1.0, 0, 0))
+        b.add_position_actuator(f'joint_limb_{side}', kp=0.05)
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))
+    return b.compile()
+
+
+def test_plane_mesh_contacts(oracle):
+    """Convex mesh geoms against the plane (the mesh part): the contact lists (the up-to-4 deepest penetrating
+    hull vertices per geom, deepest first), the forces and the state after a drop match the oracle."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _mesh_walker()
+    assert m.nmeshvert == 60 + 2*24
+    n, T = 8, 60
+    rng = np.random.default_rng(12)
+    qpos = np.tile(m.qpos0, (n, 1))
+    qpos[:, 2] = 0.012 + 0.01*rng.uniform(size=n)                     # trunk partly below its rest height: vertices touch
+    ang = 0.2*rng.normal(size=(n, 3)); qpos[:, 3] = 1.0; qpos[:, 4:7] = 0.5*ang
+    qpos[:, 3:7] /= np.linalg.norm(qpos[:, 3:7], axis=1, keepdims=True)
+    qpos[:, 7:] = rng.uniform(-0.3, 0.3, (n, m.nq - 7))
+    qvel = 0.05*rng.normal(size=(n, m.nv))
+    phys = BatchedPhysics(m, n)
+    q32, v32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref) and ncon_ref.max() >= 5 and ncon_ref.min() >= 1
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)))
+    for k, tol in (('xpos', 2e-6), ('qvel', 2e-3), ('qpos', 1e-5)):
+        assert _relerr(getattr(d, k).cpu().numpy(), ref[k]) < tol, (k, _relerr(getattr(d, k).cpu().numpy(), ref[k]))
+    for e in range(n):
+        fd = fds[e]
+        got = d.contact.cpu().numpy()[e, :fd['ncon']]
+        assert np.allclose(got[:, :3], fd['contact'][:fd['ncon'], :3], atol=1e-6)
+        f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4)
+        assert np.allclose(got[:, 12], f.sum(1), rtol=2e-2, atol=2e-4)
+    phys.step(T - 1)                      # a short drop: the body comes to rest on its hull in both implementations
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=T)
+    assert int(d.status.abs().sum()) == 0
+    assert np.abs(d.qpos.cpu().numpy()[:, :3] - ref['qpos'][:, :3]).max() < 2e-3
+
+
+def test_mesh_on_heightfield_and_fused_rows(oracle):
+    """Mesh geoms on a heightfield through the fused loop: contact-sensor rows of the mesh-footed limbs and the state
+    match the oracle's fused loop."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    from farms_mujoco_amd.model import ModelBuilder
+    rng = np.random.default_rng(2)
+
+    def cloud(n_, a, b_, c):
+        v = rng.normal(size=(n_, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True)
+        return v*np.array([a, b_, c])
+    b = ModelBuilder('meshbot_h', timestep=1e-3)
+    b.options['max_contacts'] = 16
+    b.add_body('trunk', pos=(0, 0, 0.08), mass=0.5, inertia=(2e-4, 6e-4, 7e-4), joint='free')
+    b.add_mesh_geom('trunk', cloud(40, 0.06, 0.03, 0.015), friction=(0.8, 0, 0))
+    for side, y in (('L', 0.04), ('R', -0.04)):
+        b.add_body(f'limb_{side}', parent='trunk', pos=(0.03, y, 0.0), mass=0.05, inertia=(2e-6, 8e-6, 8e-6),
+                   joint='hinge', axis=(0, 1, 0), damping=1e-3, limited=True, range=(-0.6, 0.6))
+        b.add_mesh_geom(f'limb_{side}', cloud(16, 0.03, 0.008, 0.008), pos=(0.03, 0, -0.02), friction=(1.0, 0, 0))
+        b.add_position_actuator(f'joint_limb_{side}', kp=0.05)
+    xs = np.linspace(-1, 1, 9)
+    b.add_hfield(0.5 + 0.5*np.outer(np.sin(2.0*xs), np.cos(1.5*xs)), (0.4, 0.4, 0.03, 0.1), friction=(0, 0, 0))
+    m = b.compile()
+    n, T = 6, 50
+    pairs = [('limb_L', ''), ('limb_R', ''), ('trunk', '')]
+    data = AnimatData(m.timestep, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    sim = Simulation(m, m.body_names[1], SimulationOptions(timestep=m.timestep, n_iterations=T), n_envs=n, data=data, buffer_size=T)
+    sim.reset()
+    d = sim.physics.data
+    q0 = np.tile(m.key_qpos, (n, 1)); q0[:, 0] = rng.uniform(-0.15, 0.15, n); q0[:, 1] = rng.uniform(-0.15, 0.15, n); q0[:, 2] = 0.05
+    q0[:, 7:] += rng.uniform(-0.2, 0.2, (n, m.nq - 7))
+    d.qpos[:] = torch.as_tensor(q0, dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    q32 = d.qpos.cpu().numpy().astype(np.float64); v32 = d.qvel.cpu().numpy().astype(np.float64)
+    st = dict(qpos=q32, qvel=v32)
+    fds = [oracle.forward_debug(m, q32[e], v32[e]) for e in range(n)]
+    for k in ('xpos', 'xquat', 'xipos'):
+        st[k] = np.array([fd[k] for fd in fds])
+    sd = np.array([fd['sensordata'] for fd in fds]); sd[:, 6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0
+    st['sensordata'] = sd
+    assert sim.task.fusable()
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    g2d = sim.task.maps['sensors']['geompair2data']
+    ref = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                           n_contact_rows=len(pairs), n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    rows = data.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
+    scale = np.abs(want[..., :9]).max()
+    assert scale > 0.05 and np.abs(rows[..., :9] - want[..., :9]).max()/scale < 3e-2
+    assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3

@@ -297,3 +297,52 @@ def test_self_collision_capsules_closest_points(oracle):
     assert abs(ct[17] - (0.05 - 2*r)) < 1e-12 and np.allclose(ct[3:6], [0, 1, 0], atol=1e-12)
     assert abs(ct[0] - 0.05) < 1e-9                       # middle of the overlap [0.0, 0.1] of the two segments
     assert fd['qacc'][1] > 0 > fd['qacc'][0] and abs(fd['qacc'][0] + fd['qacc'][1]) < 1e-9*abs(fd['qacc'][1])
+
+
+def _mesh_body(verts, quat=(1, 0, 0, 0), z=0.0, mass=0.4, hull=True):
+    b = ModelBuilder('meshbody', timestep=1e-3)
+    b.add_body('p', 'world', pos=(0, 0, z), quat=quat, mass=mass, inertia=(4e-4, 4e-4, 4e-4), joint='free')
+    b.add_mesh_geom('p', verts, friction=(1.0, 0, 0), hull=hull)
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))
+    b.options['max_contacts'] = 8
+    return b.compile()
+
+
+def test_mesh_of_a_box_equals_the_box(oracle):
+    """A convex mesh given as the 8 corners of a box (plus interior points, which the hull drops) makes the contacts of the
+    box geom: the same points and depths when at most 4 corners penetrate, and it settles carrying the weight."""
+    hx, hy, hz = 0.05, 0.03, 0.02
+    corners = np.array([[sx*hx, sy*hy, sz*hz] for sz in (-1, 1) for sy in (-1, 1) for sx in (-1, 1)], float)
+    cloud = np.concatenate([corners, 0.5*corners, np.zeros((1, 3))])
+    c, s = np.cos(0.15), np.sin(0.15)
+    for quat, z in (((1, 0, 0, 0), hz - 1e-3), ((c, s, 0, 0), hz + 0.002), ((c, 0, s, 0), hz + 0.004)):
+        mesh = _mesh_body(cloud, quat=quat, z=z)
+        assert mesh.nmeshvert == 8 and mesh.geom_vertnum[mesh.geom_type == 7][0] == 8          # interior points dropped
+        box = _prism('box', (hx, hy, hz), quat=quat, z=z)
+        fm = oracle.forward_debug(mesh, mesh.qpos0, np.zeros(6)); fb = oracle.forward_debug(box, box.qpos0, np.zeros(6))
+        assert fm['ncon'] == fb['ncon'] and 1 <= fm['ncon'] <= 4
+        km = np.lexsort(fm['contact'][:fm['ncon'], :3].T); kb = np.lexsort(fb['contact'][:fb['ncon'], :3].T)
+        assert np.allclose(fm['contact'][:fm['ncon']][km][:, :3], fb['contact'][:fb['ncon']][kb][:, :3], atol=1e-12)
+        assert np.allclose(fm['contact'][:fm['ncon']][km][:, 17], fb['contact'][:fb['ncon']][kb][:, 17], atol=1e-12)
+        assert np.all(np.diff(fm['contact'][:fm['ncon'], 17]) >= -1e-15)                   # deepest first
+    o = oracle.step(mesh, mesh.qpos0[None], np.zeros((1, 6)), n_steps=2500)
+    fd = oracle.forward_debug(mesh, o['qpos'][0], o['qvel'][0])
+    assert abs(fd['efc_force'][:fd['nefc']].sum() - 0.4*9.81) < 2e-3 and abs(o['qvel'][0]).max() < 1e-3
+
+
+def test_mesh_keeps_its_four_deepest_vertices(oracle):
+    """More than four penetrating vertices: the four deepest make the contacts, deepest first, equal depths in vertex order;
+    a mesh whose bounding sphere clears the ground gives none."""
+    rng = np.random.default_rng(3)
+    v = rng.normal(size=(40, 3)); v /= np.linalg.norm(v, axis=1, keepdims=True); v *= 0.05        # points on a sphere: all on the hull
+    m = _mesh_body(v, z=0.03, hull=True)
+    fd = oracle.forward_debug(m, m.qpos0, np.zeros(6))
+    vv = m.mesh_vert                                    # hull order = input order here
+    depth = vv[:, 2] + 0.03
+    want = np.argsort(depth, kind='stable')[:4]
+    assert (depth < 0).sum() > 4 and fd['ncon'] == 4
+    assert np.allclose(fd['contact'][:4, 17], depth[want], atol=1e-12)
+    assert np.allclose(fd['contact'][:4, :2], vv[want][:, :2], atol=1e-12)
+    assert np.allclose(fd['contact'][:4, 2], 0.5*depth[want], atol=1e-12)                    # midway between vertex and plane
+    far = _mesh_body(v, z=0.0501)
+    assert oracle.forward_debug(far, far.qpos0, np.zeros(6))['ncon'] == 0

@@ -260,3 +260,38 @@ def test_self_collisions_become_contact_pairs(sdf_path):
     # without an arena the pairs alone switch the collision geoms on
     m2 = setup_model(SimulationOptions(timestep=1e-3), ao, ArenaOptions())
     assert m2.npair == 1 and m2.ngeom == 2 and m2.max_contacts >= 32
+
+
+def test_mesh_collision_from_obj_and_stl(tmp_path):
+    """SDF mesh collisions (reference mjcf.py:270-413): the vertices of an .obj / binary .stl / ascii .stl file, scaled by
+    the element's <scale>, become a convex mesh geom (hull vertices only); the MJCF export carries them as a mesh asset."""
+    import struct
+    from farms_mujoco_amd.io.mesh import read_vertices
+    from farms_mujoco_amd.io.sdf import ModelSDF
+    from farms_mujoco_amd.simulation.mjcf import sdf2model, model2mjcf_xml
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    faces = [(0, 2, 1), (0, 1, 3), (0, 3, 2), (1, 2, 3)]
+    (tmp_path / 'tet.obj').write_text('# tetrahedron\n' + ''.join(f'v {a} {b} {c}\n' for a, b, c in tet) + 'vn 0 0 1\n'
+                                      + ''.join(f'f {i + 1} {j + 1} {k + 1}\n' for i, j, k in faces))
+    with open(tmp_path / 'tet.stl', 'wb') as f:
+        f.write(b'binary stl'.ljust(80, b' ') + struct.pack('<I', len(faces)))
+        for i, j, k in faces:
+            f.write(struct.pack('<12fH', 0, 0, 0, *tet[i], *tet[j], *tet[k], 0))
+    (tmp_path / 'tet_ascii.stl').write_text('solid t\n' + ''.join(
+        'facet normal 0 0 0\n outer loop\n' + ''.join(f'  vertex {tet[v][0]} {tet[v][1]} {tet[v][2]}\n' for v in fc) + ' endloop\nendfacet\n'
+        for fc in faces) + 'endsolid t\n')
+    for name in ('tet.obj', 'tet.stl', 'tet_ascii.stl'):
+        v = read_vertices(str(tmp_path / name), scale=(0.1, 0.2, 0.3))
+        assert sorted(map(tuple, np.round(v, 12))) == sorted(map(tuple, tet*[0.1, 0.2, 0.3])), name
+    (tmp_path / 'm.sdf').write_text('''<sdf version="1.6"><model name="m">
+      <link name="base"><pose>0 0 0.2 0 0 0</pose>
+        <inertial><mass>0.3</mass><inertia><ixx>1e-4</ixx><iyy>1e-4</iyy><izz>1e-4</izz></inertia></inertial>
+        <collision name="c"><pose>0.01 0 0 0 0 0</pose><geometry><mesh><uri>tet.obj</uri><scale>0.1 0.1 0.1</scale></mesh></geometry></collision>
+      </link></model></sdf>''')
+    m = sdf2model(ModelSDF.read(str(tmp_path / 'm.sdf'))[0], plane=True, use_collisions=True)
+    g = int(np.nonzero(m.geom_type == 7)[0][0])
+    assert m.nmeshvert == 4 and m.geom_vertnum[g] == 4 and m.geom_vertadr[g] == 0
+    assert sorted(map(tuple, np.round(m.mesh_vert, 12))) == sorted(map(tuple, 0.1*tet))
+    assert np.allclose(m.geom_pos[g], [0.01, 0, 0]) and abs(m.geom_size[g][2] - 0.1) < 1e-12      # bounding radius about the geom origin
+    xml = model2mjcf_xml(m)
+    assert '<mesh name="mesh_%d"' % g in xml and 'type="mesh"' in xml
