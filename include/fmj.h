@@ -133,7 +133,8 @@ typedef struct fmj_model {
 
   /* collision geoms [ngeom] (config 4: animat geoms vs arena; reference mjcf.py:251-527).  Supported pairs: a ground geom
    * (world-attached plane, or ONE world-attached heightfield, reference mjcf.py:486-522 / task.py:108-123) against sphere
-   * (1 contact), capsule (2: segment ends), cylinder (rim points: up to 4) and box (first 4 penetrating corners).  The
+   * (1 contact), capsule (2: segment ends), cylinder (rim points: up to 4), box (first 4 penetrating corners) and convex
+   * mesh (its 4 deepest penetrating vertices, see mesh_vert below).  The
    * heightfield is met as the plane of the grid triangle under each candidate point ("plane per cell").  At most 192
    * constraint rows per env: limited joints + 4 * max_contacts <= 192. */
   const int32_t* geom_type;     /* FMJ_GEOM_* */
