@@ -7,7 +7,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def random_tree(seed, contacts=False):
+def random_tree(seed, contacts=False, meshes=False):
     from farms_mujoco_amd.model import ModelBuilder, euler2quat, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_PLANE
     rng = np.random.default_rng(seed)
     nb = int(rng.integers(3, 22))
@@ -43,7 +43,7 @@ def random_tree(seed, contacts=False):
             b.add_body(name, parent, pos=rng.normal(size=3)*0.08, quat=euler2quat(rng.normal(size=3)*0.5), **jkw, **kw)
         names.append(name)
         if contacts and rng.random() < 0.7:
-            kind = int(rng.integers(0, 4))
+            kind = int(rng.integers(0, 5 if meshes else 4))
             gk = dict(pos=rng.normal(size=3)*0.02, quat=euler2quat(rng.normal(size=3)), friction=(float(rng.uniform(0.3, 1.0)), 0, 0))
             if kind == 0:
                 b.add_geom(name, GEOM_SPHERE, (float(rng.uniform(0.02, 0.05)),), **gk)
@@ -51,8 +51,11 @@ def random_tree(seed, contacts=False):
                 b.add_geom(name, GEOM_CAPSULE, (float(rng.uniform(0.015, 0.03)), float(rng.uniform(0.02, 0.06))), **gk)
             elif kind == 2:
                 b.add_geom(name, GEOM_BOX, tuple(rng.uniform(0.015, 0.05, 3)), **gk)
-            else:
+            elif kind == 3:
                 b.add_geom(name, GEOM_CYLINDER, (float(rng.uniform(0.02, 0.05)), float(rng.uniform(0.01, 0.05))), **gk)
+            else:                       # convex mesh: a random point cloud (its hull), off-centre in the geom frame
+                cloud = rng.normal(size=(int(rng.integers(5, 40)), 3))*rng.uniform(0.01, 0.04, 3) + rng.normal(size=3)*0.01
+                b.add_mesh_geom(name, cloud, **gk)
     if contacts:
         b.add_geom('world', GEOM_PLANE, (0, 0, 0), pos=(0, 0, -0.05), friction=(0.2, 0, 0))
         b.options['max_contacts'] = 32
@@ -161,3 +164,47 @@ def test_random_tree_with_limits_and_contacts(oracle, seed):
             f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4).sum(1)
             got = d.contact.cpu().numpy()[e, :fd['ncon'], 12]
             assert np.allclose(got, f, rtol=3e-2, atol=2e-3*max(1.0, np.abs(f).max())), (seed, e, got, f)
+
+
+@pytest.mark.parametrize('seed', range(300, 310))
+def test_random_tree_with_mesh_geoms(oracle, seed):
+    """Random trees whose collision shapes include convex meshes (random point clouds, hulls of 4 to ~30 vertices, rotated
+    and off-centre), with limits, over a plane: contact counts, the state after one step and the contact forces vs the
+    oracle (models with meshes run the PAIRS instantiation of the constraint kernel)."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = random_tree(seed, contacts=True, meshes=True)
+    if m is None or m.nv == 0 or m.nmeshvert == 0:
+        pytest.skip('degenerate draw')
+    rng = np.random.default_rng(5000 + seed)
+    n = 6
+    qpos = np.tile(m.qpos0, (n, 1)) + rng.uniform(-0.4, 0.4, (n, m.nq))
+    for j in range(m.njnt):
+        if m.jnt_type[j] == 0:
+            a = m.jnt_qposadr[j]; q = rng.normal(size=(n, 4)); qpos[:, a+3:a+7] = q/np.linalg.norm(q, axis=1, keepdims=True)
+            qpos[:, a+2] = rng.uniform(-0.05, 0.1, n)
+    qvel = rng.normal(size=(n, m.nv))*0.2
+    phys = BatchedPhysics(m, n)
+    d = phys.data
+    f32 = lambda a: torch.as_tensor(a, dtype=torch.float32)
+    d.qpos[:] = f32(qpos); d.qvel[:] = f32(qvel)
+    r64 = lambda t: t.cpu().numpy().astype(np.float64)
+    q32, v32 = r64(d.qpos), r64(d.qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    assert int((d.status & ~4).abs().sum()) == 0
+    fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu) if m.nu else None) for e in range(n)]
+    ncon_ref = np.array([fd['ncon'] for fd in fds])
+    assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref), (d.ncon.cpu().numpy(), ncon_ref)
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)) if m.nu else None)
+    for k, tol in (('xpos', 5e-6), ('qvel', 3e-3), ('qpos', 2e-5)):
+        a = r64(getattr(d, k)); bb = ref[k]
+        e_ = np.abs(a - bb).max()/max(np.abs(bb).max(), 1e-9)
+        assert e_ < tol, (seed, m.nbody, m.nv, ncon_ref, k, e_)
+    for e in range(n):
+        fd = fds[e]
+        if fd['ncon']:
+            got = d.contact.cpu().numpy()[e, :fd['ncon']]
+            assert np.allclose(got[:, :3], fd['contact'][:fd['ncon'], :3], atol=2e-6), (seed, e)
+            f = fd['efc_force'][fd['nefc'] - 4*fd['ncon']:fd['nefc']].reshape(-1, 4).sum(1)
+            assert np.allclose(got[:, 12], f, rtol=3e-2, atol=2e-3*max(1.0, np.abs(f).max())), (seed, e, got[:, 12], f)
