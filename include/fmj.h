@@ -44,7 +44,8 @@ enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CA
  * reference simulation.py:157-161,176-179).  An env whose status carries one of the BAD* bits is FROZEN: from the
  * step that found the bad value on (and in every later launch until the caller clears the status word) its state is
  * left at the last finite values, it is no longer integrated and none of its ring-buffer rows are written
- * (SURVEY 5).  FMJ_WARN_CONTACTFULL only reports a truncated contact list and does not freeze. */
+ * (the fused loop writes the links / xfrc row of iteration it + 1 in step it, so the row after the last good
+ * step may already be there, computed from that step's finite state).  FMJ_WARN_CONTACTFULL only reports a truncated contact list and does not freeze. */
 enum { FMJ_WARN_BADQPOS = 1, FMJ_WARN_BADQVEL = 2, FMJ_WARN_BADQACC = 4, FMJ_WARN_CONTACTFULL = 8 };
 #define FMJ_WARN_FREEZE (FMJ_WARN_BADQPOS | FMJ_WARN_BADQVEL | FMJ_WARN_BADQACC)
 
