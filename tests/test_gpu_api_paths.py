@@ -460,3 +460,30 @@ def test_drag_forces_single_link(oracle):
         z = sim.task.data.sensors.links.array[0, :, int(h.links_indices[i]), 2]
         assert torch.equal(wet, z <= h.water._surface) and bool(wet.any()) and not bool(wet.all())
         assert torch.all(row[~wet] == 3.0)
+
+
+def test_postprocess_writes_the_log_and_options(tmp_path):
+    """Simulation.postprocess (reference simulation.py:181-213): the sensor log of the iterations run (``simulation.hdf5``, or
+    ``.npz`` with the same keys where h5py is absent), the simulation and animat options as YAML; the log reads back
+    into an AnimatData with the rows the run left in the ring buffer; save_mjcf_xml writes the compiled model."""
+    import os
+    import torch
+    import yaml
+    from farms_mujoco_amd.data import AnimatData
+    sim, m, _ = _swim_sim(3, 30)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    sim.postprocess(iteration=sim.iteration, log_path=str(tmp_path))
+    logs = [f for f in os.listdir(tmp_path) if f.startswith('simulation.') and f.rsplit('.', 1)[1] in ('hdf5', 'npz')]
+    assert len(logs) == 1
+    back = AnimatData.from_file(str(tmp_path / logs[0]))
+    for k in ('links', 'joints', 'xfrc'):
+        a = getattr(sim.task.data.sensors, k); b = getattr(back.sensors, k)
+        assert list(map(str, a.names)) == list(map(str, b.names))
+        assert np.array_equal(a.array.cpu().numpy(), b.array.cpu().numpy()), k
+    assert abs(back.timestep - m.timestep) < 1e-15
+    opts = yaml.safe_load(open(tmp_path / 'simulation_options.yaml'))
+    assert opts['n_iterations'] == 30 and abs(opts['timestep'] - m.timestep) < 1e-15
+    assert os.path.exists(tmp_path / 'animat_options.yaml')
+    xml = open(sim.save_mjcf_xml(str(tmp_path / 'model.xml'))).read()
+    assert xml.count('<body ') == m.nbody - 1 and 'solver="PGS"' in xml
