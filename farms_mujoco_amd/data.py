@@ -121,3 +121,11 @@ class AnimatData:
         for k, a in arrays.items():
             getattr(out.sensors, k).array.copy_(torch.as_tensor(a))
         return out
+
+
+if __name__ == '__main__':      # python -m farms_mujoco_amd.data in.npz out.hdf5  (on a machine that has h5py)
+    import sys
+    if len(sys.argv) != 3:
+        sys.exit('usage: python -m farms_mujoco_amd.data <log written by to_file> <output .npz | .hdf5>')
+    out = AnimatData.from_file(sys.argv[1]).to_file(sys.argv[2])
+    print(out)
