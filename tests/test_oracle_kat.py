@@ -259,3 +259,76 @@ def test_physics2data_layout(oracle):
     acts = [a for a in range(m.nu) if m.actuator_jntid[a] == jid]
     assert len(acts) == 3 and np.isclose(joints[0, j, 8], sum(sd[0, act + a] for a in acts)/48.0)
     assert np.isclose(joints[0, j, 9], sd[0, 6*(m.nbody-1) + 3*j + 2]/48.0)
+
+
+# ---- closed forms from the textbook, derived independently of the recursive algorithms -------------------
+
+def test_double_pendulum_textbook_accelerations(oracle):
+    """Point-mass double pendulum: the angular accelerations of the Lagrangian closed form (absolute angles from the
+    downward vertical; e.g. the standard result with 2 m1 + m2 - m2 cos(2 th1 - 2 th2) in the denominator) at random
+    states, against qacc_smooth of the oracle (relative joint angles).  Nothing of CRBA / RNE enters the expected value."""
+    m1, m2, L1, L2, g = 0.7, 0.4, 0.35, 0.25, 9.81
+    b = ModelBuilder('dp_point', timestep=1e-3)
+    eps = 1e-12                                   # point masses: body inertia negligible
+    b.add_body('a', 'world', mass=m1, ipos=(0, 0, -L1), inertia=(eps, eps, eps), joint='hinge', axis=(0, 1, 0))
+    b.add_body('b', 'a', pos=(0, 0, -L1), mass=m2, ipos=(0, 0, -L2), inertia=(eps, eps, eps), joint='hinge', axis=(0, 1, 0))
+    m = b.compile()
+    rng = np.random.default_rng(0)
+    for _ in range(20):
+        th1, th2 = rng.uniform(-2.5, 2.5, 2)
+        w1, w2 = rng.uniform(-3, 3, 2)
+        q = np.array([th1, th2 - th1]); v = np.array([w1, w2 - w1])
+        o = oracle.forward_debug(m, q, v)
+        # rotation about +y by th moves the hanging mass (0,0,-L) to (-L sin th, 0, -L cos th): the textbook's angle with x -> -x,
+        # which leaves the equations unchanged (they are odd in the pair of angles)
+        den = 2*m1 + m2 - m2*np.cos(2*th1 - 2*th2)
+        a1 = (-g*(2*m1 + m2)*np.sin(th1) - m2*g*np.sin(th1 - 2*th2)
+              - 2*np.sin(th1 - th2)*m2*(w2*w2*L2 + w1*w1*L1*np.cos(th1 - th2)))/(L1*den)
+        a2 = (2*np.sin(th1 - th2)*(w1*w1*L1*(m1 + m2) + g*(m1 + m2)*np.cos(th1) + w2*w2*L2*m2*np.cos(th1 - th2)))/(L2*den)
+        assert np.allclose(o['qacc_smooth'], [a1, a2 - a1], rtol=1e-8, atol=1e-8), (o['qacc_smooth'], a1, a2 - a1)
+
+
+def test_torsion_spring_frequency_and_damped_decay(oracle):
+    """One hinge with joint stiffness k, inertia I about the axis: undamped it oscillates at sqrt(k / I) (period from zero
+    crossings); with damping c the envelope decays like exp(-c t / (2 I))."""
+    I, k, h = 2e-3, 0.8, 1e-4
+    def build(c):
+        b = ModelBuilder('spring', timestep=h, gravity=(0, 0, 0))
+        b.add_body('a', 'world', mass=0.1, inertia=(I, I, I), joint='hinge', axis=(0, 0, 1), stiffness=k, damping=c)
+        return b.compile()
+    m = build(0.0)
+    n = 20000
+    qs = []
+    q, v = np.array([[0.3]]), np.array([[0.0]])
+    for _ in range(n//100):
+        o = oracle.step(m, q, v, n_steps=100); q, v = o['qpos'], o['qvel']; qs.append(q[0, 0])
+    qs = np.array(qs); t = (np.arange(len(qs)) + 1)*100*h
+    zc = t[:-1][np.sign(qs[:-1]) != np.sign(qs[1:])]
+    period = 2*np.mean(np.diff(zc))
+    assert abs(period - 2*np.pi/np.sqrt(k/I)) < 2e-2*period
+    c = 4e-3
+    m = build(c)
+    o = oracle.step(m, np.array([[0.3]]), np.array([[0.0]]), n_steps=n)
+    amp = np.hypot(o['qpos'][0, 0], o['qvel'][0, 0]/np.sqrt(k/I - (c/(2*I))**2))
+    assert abs(amp/0.3 - np.exp(-c*n*h/(2*I))) < 2e-2
+
+
+def test_sinking_link_terminal_velocity(oracle):
+    """A body heavier than water sinks at the speed where the drag sign(v) v^2 c equals weight minus buoyancy
+    (drag.pyx:83-88,139-146): v_t = sqrt((m g - buoyancy) / (viscosity c_z))."""
+    from farms_mujoco_amd.model import ModelBuilder as MB
+    mass, cz, density, height = 0.5, 2.0, 1500.0, 0.05
+    b = MB('sinker', timestep=1e-3)
+    b.add_body('a', 'world', pos=(0, 0, -1.0), mass=mass, inertia=(1e-3, 1e-3, 1e-3), joint='free')
+    b.set_swimming('a', density=density, drag_coefficients=[[-0.5, -0.5, -cz], [-1e-3, -1e-3, -1e-3]], height=height)
+    m = b.compile()
+    water = dict(surface=0.0, velocity=[0, 0, 0], viscosity=1.0, gravity=-9.81, use_buoyancy=True)
+    fd = oracle.forward_debug(m, m.qpos0, np.zeros(6))
+    st = dict(qpos=m.qpos0[None], qvel=np.zeros((1, 6)), xpos=fd['xpos'][None], xquat=fd['xquat'][None], xipos=fd['xipos'][None],
+              sensordata=fd['sensordata'][None])
+    swim = dict(links_index=[0], xfrc_index=[0], body_index=[1], coefficients=[[[-0.5, -0.5, -cz], [-1e-3, -1e-3, -1e-3]]],
+                masses=[mass], heights=[height], densities=[density])
+    o = oracle.run_fused(m, st, 4000, swim=swim, water=water, buffer_size=1, controller=0, ctrl=np.zeros((1, 0)))
+    buoy = 1000.0*9.81*mass/density                      # fully submerged
+    vt = np.sqrt((mass*9.81 - buoy)/cz)
+    assert abs(-o['qvel'][0, 2] - vt) < 1e-3*vt, (o['qvel'][0, 2], vt)
