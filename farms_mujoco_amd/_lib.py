@@ -84,6 +84,8 @@ SYMBOLS = {
     'fmj_step': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, ctypes.c_int64, _VP]),
     'fmj_forward': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP]),
     'fmj_forward_debug': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP, _I, _VP, _VP]),
+    'fmj_step_debug': (ctypes.c_int, [_VP, ctypes.POINTER(CData), _VP, _VP, _VP]),
+    'fmj_constraint_info': (ctypes.c_int, [_VP, _I, _I, _I]),
     'fmj_drag': (ctypes.c_int, [_VP, ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits), _VP, _VP]),
     'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
                                         ctypes.c_int32, _VP]),
@@ -97,7 +99,7 @@ SYMBOLS = {
 }
 
 _lib = None
-ABI_VERSION = 3         # FMJ_ABI_VERSION of include/fmj.h
+ABI_VERSION = 4         # FMJ_ABI_VERSION of include/fmj.h
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:

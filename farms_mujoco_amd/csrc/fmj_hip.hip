@@ -156,6 +156,7 @@ struct StepArgs {
   float* ctrl_out;            // fused + wave controller: ctrl of the launch's last step (physics.data.ctrl)
   const int* env_order;       // one-env kernel: env of workgroup b (NULL: b); heavier envs first shortens a launch's tail
   float* dbg_H; float* dbg_qfrc;   // fmj_forward_debug: rows of H = M + diag(armature + h damping) [n_envs][nv][rs], qfrc_smooth [n_envs][nv]
+  float* dbg_efc; float* dbg_pgs;  // fmj_step_debug: constraint rows after the solve [n_envs][maxefc][8], dual-cost improvement per PGS sweep [n_envs][solver_iterations]
 };
 
 static_assert(alignof(DevModel) == 8 && alignof(StepArgs) == 8, "kernarg layout of (DevModel, StepArgs)");
@@ -1673,15 +1674,20 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     if (!frozen) steps_done++;
     WSYNC();
     if (jtype == FMJ_JNT_FREE && A.integrate && !frozen) {     // free joint position update (lane = root body)
-      QP[qadr] += M.h * QV[dadr]; QP[qadr + 1] += M.h * QV[dadr + 1]; QP[qadr + 2] += M.h * QV[dadr + 2];
-      const v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
-      const float n2 = dot3(w, w), rn = rsqrt_nr(n2), n = n2 * rn;
-      q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
-      qo = qnormalize(qo);
-      if (n2 >= 1e-30f) qo = qmul(qo, axisangle_small(scl3(w, rn), M.h * n));
-      QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
-      if (!(fabsf(QP[qadr]) <= 1e10f) || !(fabsf(QP[qadr + 1]) <= 1e10f) || !(fabsf(QP[qadr + 2]) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
+      // the new root position is tested before it is committed: a frozen env keeps its last finite state (include/fmj.h)
+      const float nx = QP[qadr] + M.h * QV[dadr], ny = QP[qadr + 1] + M.h * QV[dadr + 1], nz = QP[qadr + 2] + M.h * QV[dadr + 2];
+      if (!(fabsf(nx) <= 1e10f) || !(fabsf(ny) <= 1e10f) || !(fabsf(nz) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
+      else {
+        QP[qadr] = nx; QP[qadr + 1] = ny; QP[qadr + 2] = nz;
+        const v3 w = mk3(QV[dadr + 3], QV[dadr + 4], QV[dadr + 5]);
+        const float n2 = dot3(w, w), rn = rsqrt_nr(n2), n = n2 * rn;
+        q4 qo = {QP[qadr + 3], QP[qadr + 4], QP[qadr + 5], QP[qadr + 6]};
+        qo = qnormalize(qo);
+        if (n2 >= 1e-30f) qo = qmul(qo, axisangle_small(scl3(w, rn), M.h * n));
+        QP[qadr + 3] = qo.w; QP[qadr + 4] = qo.x; QP[qadr + 5] = qo.y; QP[qadr + 6] = qo.z;
+      }
     }
+    if (__any((warn & FMJ_WARN_BADQPOS) != 0)) frozen = true;   // no row of the next iteration is emitted from a bad position
     WSYNC();
     STAMP(11);  // Euler
   }
@@ -1964,6 +1970,9 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (m->geom_bodyid[g1] == m->geom_bodyid[g2]) return set_err(FMJ_ERR_ARG, "fmj_create: a contact pair joins geoms of two bodies");
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
+  if (cons && m->solver != FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements solver = PGS (FMJ_SOLVER_PGS) only");
+  if (cons && m->cone != FMJ_CONE_PYRAMIDAL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements the pyramidal friction cone only");
+  if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
@@ -2431,6 +2440,9 @@ int fmj_set_actuator_forcerange(fmj_ctx* c, int32_t nu, const int32_t* forcelimi
     lim.z = forcelimited[src] ? (float)forcerange[2 * src] : -3.0e38f;
     lim.w = forcelimited[src] ? (float)forcerange[2 * src + 1] : 3.0e38f;
   }
+  // the table is live: a step kernel of this context may still be running on a non-blocking stream, which the null-stream
+  // copy below would not wait for.  Drain the device first (this is a set-up call, task.py:253-286 runs it once).
+  HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy((void*)c->dm.atab, c->h_atab.data(), c->h_atab.size() * sizeof(float4), hipMemcpyHostToDevice));
   return FMJ_OK;
 }
@@ -2505,6 +2517,24 @@ int fmj_forward_debug(fmj_ctx* c, const fmj_data* d, int32_t disable_actuation, 
   if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_forward_debug: qpos_spring required (model has joint stiffness)");
   A.n_steps = 1; A.integrate = 0; A.disable_actuation = disable_actuation; A.dbg_H = H_rows; A.dbg_qfrc = qfrc_smooth;
   if (row_stride) *row_stride = c->dm.rs;
+  HIP_TRY(hipSetDevice(c->device));
+  return launch_step(c, false, A, stream);
+}
+
+int fmj_constraint_info(const fmj_ctx* c, int32_t* maxefc, int32_t* max_contacts, int32_t* solver_iterations) {
+  if (!c) return set_err(FMJ_ERR_ARG, "fmj_constraint_info: NULL ctx");
+  if (maxefc) *maxefc = c->dm.maxefc;
+  if (max_contacts) *max_contacts = c->dm.max_contacts;
+  if (solver_iterations) *solver_iterations = c->dm.solver_iterations;
+  return FMJ_OK;
+}
+
+int fmj_step_debug(fmj_ctx* c, const fmj_data* d, float* efc_rows, float* pgs_improvement, void* stream) {
+  if (!c || !efc_rows) return set_err(FMJ_ERR_ARG, "fmj_step_debug: NULL argument");
+  if (!c->dm.cons) return set_err(FMJ_ERR_ARG, "fmj_step_debug: the model has no constraints");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step_debug: qpos_spring required (model has joint stiffness)");
+  A.n_steps = 1; A.integrate = 1; A.dbg_efc = efc_rows; A.dbg_pgs = pgs_improvement;
   HIP_TRY(hipSetDevice(c->device));
   return launch_step(c, false, A, stream);
 }

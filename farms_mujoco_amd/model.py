@@ -22,7 +22,7 @@ import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 5, 6, 7
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 DEFAULT_SOLREF = (0.02, 1.0)
 DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)
@@ -117,7 +117,8 @@ class ModelBuilder:
         self.actuators: List[dict] = []
         self.hfield: Optional[dict] = None
         self.pairs: List[dict] = []
-        self.options = dict(solver_iterations=50, max_contacts=0, impratio=1.0, solver_tolerance=1e-8)
+        self.options = dict(solver_iterations=50, max_contacts=0, impratio=1.0, solver_tolerance=1e-8, solver='PGS', cone='pyramidal',
+                            ls_iterations=50, ls_tolerance=0.01, noslip_iterations=0, noslip_tolerance=1e-6)
 
     def body_id(self, name: str) -> int:
         for i, b in enumerate(self.bodies):
@@ -265,8 +266,12 @@ _CMODEL_FIELDS = (
         [('nmeshvert', ctypes.c_int32), ('mesh_vert', _D), ('geom_vertadr', _I), ('geom_vertnum', _I)] +
         [('npair', ctypes.c_int32), ('pair_geom1', _I), ('pair_geom2', _I), ('pair_friction', _D), ('pair_solref', _D), ('pair_solimp', _D)] +
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
-         ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)]
+         ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)] +
+        [('solver', ctypes.c_int32), ('cone', ctypes.c_int32), ('ls_iterations', ctypes.c_int32), ('noslip_iterations', ctypes.c_int32),
+         ('ls_tolerance', ctypes.c_double), ('noslip_tolerance', ctypes.c_double)]
 )
+SOLVERS = {'pgs': 0, 'cg': 1, 'newton': 2}          # mjtSolver (include/fmj.h FMJ_SOLVER_*)
+CONES = {'pyramidal': 0, 'elliptic': 1}            # mjtCone
 
 
 class _CModel(ctypes.Structure):
@@ -465,6 +470,10 @@ class Model:
         m.max_contacts = int(b.options['max_contacts'])
         m.impratio = float(b.options['impratio'])
         m.solver_tolerance = float(b.options['solver_tolerance'])
+        m.solver = SOLVERS[str(b.options.get('solver', 'PGS')).lower()]
+        m.cone = CONES[str(b.options.get('cone', 'pyramidal')).lower()]
+        m.ls_iterations = int(b.options.get('ls_iterations', 50)); m.ls_tolerance = float(b.options.get('ls_tolerance', 0.01))
+        m.noslip_iterations = int(b.options.get('noslip_iterations', 0)); m.noslip_tolerance = float(b.options.get('noslip_tolerance', 1e-6))
 
         # swimming links, in body order (reference drag.pyx:353-385)
         m.swimming = []
@@ -540,6 +549,9 @@ class Model:
         c.impratio = self.impratio
         c.solver_tolerance = self.solver_tolerance
         c.meaninertia = self.meaninertia
+        c.solver = int(getattr(self, 'solver', 0)); c.cone = int(getattr(self, 'cone', 0))
+        c.ls_iterations = int(getattr(self, 'ls_iterations', 50)); c.ls_tolerance = float(getattr(self, 'ls_tolerance', 0.01))
+        c.noslip_iterations = int(getattr(self, 'noslip_iterations', 0)); c.noslip_tolerance = float(getattr(self, 'noslip_tolerance', 1e-6))
         c.hfield_nrow, c.hfield_ncol = int(getattr(self, 'hfield_nrow', 0)), int(getattr(self, 'hfield_ncol', 0))
         c.hfield_size = (ctypes.c_double*4)(*np.asarray(getattr(self, 'hfield_size', np.zeros(4)), float))
         hd = getattr(self, 'hfield_data', None)

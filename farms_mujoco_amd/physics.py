@@ -114,6 +114,17 @@ class BatchedPhysics:
             stride = 0
         _lib.check(self._lib.fmj_step(self._ctx, ctypes.byref(c), int(nstep), stride, _stream_ptr(self.device)))
 
+    def step_debug(self, want_pgs: bool = True):
+        """One mj_step through ``fmj_step_debug``: returns ``(efc_rows [n_envs, maxefc, 8], pgs_improvement [n_envs,
+        solver_iterations] or None)`` next to the usual state update (tests of the constraint solve; not the product path)."""
+        me, mc, it = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        _lib.check(self._lib.fmj_constraint_info(self._ctx, ctypes.byref(me), ctypes.byref(mc), ctypes.byref(it)))
+        rows = torch.zeros(self.n_envs, max(me.value, 1), 8, device=self.device)
+        imp = torch.full((self.n_envs, max(it.value, 1)), float('nan'), device=self.device) if want_pgs else None
+        c = self._cdata()
+        _lib.check(self._lib.fmj_step_debug(self._ctx, ctypes.byref(c), _ptr(rows), _ptr(imp), _stream_ptr(self.device)))
+        return rows, imp
+
     def check_invalid_state(self):
         """Raise PhysicsError if any env reported a bad-state warning (lazy, one sync)."""
         bad = torch.nonzero(self.data.status).flatten()

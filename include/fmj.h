@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMJ_ABI_VERSION 3
+#define FMJ_ABI_VERSION 4
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -38,6 +38,10 @@ enum {
 
 /* ---- joint / geom enums (values follow MuJoCo's mjtJoint / mjtGeom) ---------------------- */
 enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, FMJ_JNT_HINGE = 3 };
+/* constraint solver and friction cone (values follow MuJoCo's mjtSolver / mjtCone; reference mjcf.py:1342-1353 forwards
+ * simulation_options.solver / .cone to the option block, its own fallbacks being 'Newton' and 'pyramidal') */
+enum { FMJ_SOLVER_PGS = 0, FMJ_SOLVER_CG = 1, FMJ_SOLVER_NEWTON = 2 };
+enum { FMJ_CONE_PYRAMIDAL = 0, FMJ_CONE_ELLIPTIC = 1 };
 enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6, FMJ_GEOM_MESH = 7 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
@@ -178,7 +182,14 @@ typedef struct fmj_model {
   int32_t max_contacts;         /* per environment */
   double impratio;
   double solver_tolerance;
-  double meaninertia;           /* mjModel.stat.meaninertia: mean diagonal of M at qpos0 (PGS termination scale) */
+  double meaninertia;           /* mjModel.stat.meaninertia: mean diagonal of M at qpos0 (solver termination scale) */
+  /* ABI 4 */
+  int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353) */
+  int32_t cone;                 /* FMJ_CONE_*:   option.cone   (mjcf.py:1342-1347) */
+  int32_t ls_iterations;        /* Newton / CG line-search iterations (MuJoCo option.ls_iterations, default 50); <= 0: 50 */
+  int32_t noslip_iterations;    /* option.noslip_iterations (mjcf.py:1392-1397); 0 = off */
+  double ls_tolerance;          /* option.ls_tolerance (default 0.01); <= 0: 0.01 */
+  double noslip_tolerance;      /* option.noslip_tolerance (mjcf.py:1398-1403) */
 } fmj_model;
 
 /* ---- per-env device buffers for the physics step -------------------------------------------
@@ -266,7 +277,8 @@ int fmj_set_swimming(fmj_ctx* ctx, int32_t ns, int32_t n_xfrc_rows, const int32_
 /* Run-time rewrite of the actuator force limits: what ExperimentTask.initialize_control does to
  * physics.named.model.actuator_forcelimited / actuator_forcerange (reference task.py:253-286: position and velocity
  * actuators of motors that are not position-controlled get forcerange = [0, 0]).  forcelimited [nu], forcerange
- * [nu,2]: HOST pointers, copied; the device tables are refreshed before the next launch. */
+ * [nu,2]: HOST pointers, copied; the call drains the device (hipDeviceSynchronize) and then refreshes the device table, so it is
+ * ordered against launches of this context on any stream. */
 int fmj_set_actuator_forcerange(fmj_ctx* ctx, int32_t nu, const int32_t* forcelimited, const double* forcerange);
 
 /* link / joint readout maps (get_physics2data_maps, reference physics.py:188-393):
@@ -292,6 +304,17 @@ int fmj_forward(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, void
  * passive - bias + actuation + J' xfrc_applied.  Not on the product path. */
 int fmj_forward_debug(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation, float* H_rows, int32_t* row_stride,
                       float* qfrc_smooth, void* hip_stream);
+
+/* Diagnostic twin of fmj_step for ONE step of a model with constraints (parity tests of the constraint solve; the
+ * reference reads the same quantities from mjData.efc_* after mj_step).  Besides stepping, it stores per env the
+ * constraint rows as the solver left them - efc_rows [n_envs, maxefc, 8] DEVICE = {pos, aref, R (after the pyramidal rule),
+ * b = J qacc_smooth - aref, force, R before the pyramidal rule, int32 bits: row kind (bit 30 = contact) | joint dof or
+ * contact index, mu}, rows ordered as MuJoCo orders them (limits by joint and side, then 4 per contact); the number of
+ * rows of an env is (limited sides active) + 4 * ncon - and, if pgs_improvement != NULL [n_envs, solver_iterations] DEVICE,
+ * the decrease of the dual cost achieved by every PGS sweep that ran (never negative for a correct sweep; entries of sweeps
+ * that did not run are left untouched).  maxefc / solver_iterations: fmj_constraint_info.  Not on the product path. */
+int fmj_step_debug(fmj_ctx* ctx, const fmj_data* d, float* efc_rows, float* pgs_improvement, void* hip_stream);
+int fmj_constraint_info(const fmj_ctx* ctx, int32_t* maxefc, int32_t* max_contacts, int32_t* solver_iterations);
 
 /* SwimmingHandler.step(iteration) (reference drag.pyx:389-411 -> drag_forces :152-268) for
  * every env: reads rows->links, writes rows->xfrc (rows of links above the surface are left

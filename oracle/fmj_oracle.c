@@ -29,9 +29,18 @@
 
 /* diagnostics: sweeps the last PGS solve ran (single-threaded use only) */
 static int g_last_pgs_iterations = 0;
-int fmjo_last_pgs_iterations(void) { return g_last_pgs_iterations; }
+int fmjo_last_pgs_iterations(void) { return g_last_pgs_iterations; }   /* sweeps / iterations of the last solve, any solver */
 
 #include "../include/fmj.h"
+
+/* Test knob: round every stored entry of the joint-space matrices (M after mj_crb, H = M + h B before its factorisation) to
+ * fp32, and nothing else - "an fp64 engine whose only flaw is fp32 storage of the inertia matrix".  What such a run differs
+ * from the plain fp64 run by is the floor of ANY fp32 composite-rigid-body + L'DL step (the matrices are ill-conditioned:
+ * scaled condition numbers 3e4 .. 2e5 for the models here); the GPU parity tests state their velocity / acceleration bounds as
+ * small multiples of it instead of fitted numbers.  Read-only while a run is in flight. */
+static int g_fp32_storage = 0;
+void fmjo_set_fp32_storage(int on) { g_fp32_storage = on; }
+static void round_to_f32(double* a, int n) { for (int i = 0; i < n; i++) a[i] = (double)(float)a[i]; }
 
 #define MINVAL 1e-15
 #define MAXVAL 1e10
@@ -304,6 +313,7 @@ static void crb(const fmj_model* m, ws_t* w) {
     w->qM[adr] = m->dof_armature[i];
     for (int j = i; j >= 0; j = m->dof_parentid[j]) w->qM[adr++] += dotn(w->cdof + 6 * j, buf, 6);
   }
+  if (g_fp32_storage) round_to_f32(w->qM, m->nM);
 }
 
 /* sparse L'DL in MuJoCo's dof_Madr/dof_parentid storage (mj_factorI) */
@@ -791,11 +801,13 @@ static double dual_cost(const ws_t* w, const double* f) {
   return c;
 }
 
+static void solve_primal(const fmj_model* m, ws_t* w, int newton);
 static void solve_constraints(const fmj_model* m, ws_t* w) {
   int nv = m->nv, n = w->nefc;
   memset(w->qfrc_constraint, 0, nv * sizeof(double));
   memset(w->jointlimitfrc, 0, m->njnt * sizeof(double));
-  if (n == 0) { memcpy(w->qacc, w->qacc_smooth, nv * sizeof(double)); return; }
+  if (n == 0) { memcpy(w->qacc, w->qacc_smooth, nv * sizeof(double)); g_last_pgs_iterations = 0; return; }
+  if (m->solver == FMJ_SOLVER_NEWTON || m->solver == FMJ_SOLVER_CG) { solve_primal(m, w, m->solver == FMJ_SOLVER_NEWTON); return; }
   /* AR = J M^-1 J' + R ; b = J qacc_smooth - aref */
   for (int e = 0; e < n; e++) {
     double* x = w->efc_MiJT + (size_t)e * nv;
@@ -839,6 +851,189 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
   memcpy(w->qacc, w->qfrc_constraint, nv * sizeof(double));
   solve_ld(m, w->qacc, w->qLD, w->qLDiagInv);
   for (int i = 0; i < nv; i++) w->qacc[i] += w->qacc_smooth[i];
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* primal solvers: Newton and CG (mj_solNewton / mj_solCG = mj_solPrimal; MuJoCo's published algorithm, restated from
+ * its documentation [MJ-knowledge], not compiled from it).  Reference mjcf.py:1348-1359 forwards
+ * simulation_options.solver / n_solver_iters; its own fallback is 'Newton' with 1000 iterations.
+ *
+ * The problem (pyramidal cone, limits: every row unilateral):
+ *     minimise over qacc   0.5 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + sum_e s_e(J_e qacc - aref_e),
+ *     s_e(x) = 0.5 x^2 / R_e for x < 0, else 0;        force_e = -x / R_e for x < 0, else 0.
+ * Its dual is the problem PGS solves (0.5 f'(A + R) f + f'b over f >= 0), so a converged PGS and the Newton minimiser
+ * give the same forces and the same qacc = qacc_smooth + M^-1 J' f: tests/test_oracle_solvers.py holds the two to 1e-8.
+ * Newton: search = -H^-1 grad with H = M + J_active' D J_active (dense Cholesky); CG: Polak-Ribiere on the M^-1
+ * preconditioned gradient.  Line search: exact derivatives of the piecewise-quadratic cost along the search line, Newton
+ * steps on phi' from alpha = 0 until phi' changes sign, then Newton safeguarded by the bracket, to
+ * |phi'| < tolerance * ls_tolerance * |search| / scale - the ingredients of MuJoCo's PrimalLineSearch; the iterates inside
+ * the bracket may differ from MuJoCo's, the minimiser they close in on cannot. */
+
+static void mul_M_sparse(const fmj_model* m, const double* M, const double* v, double* res) {
+  int nv = m->nv;
+  for (int i = 0; i < nv; i++) res[i] = 0;
+  for (int i = 0; i < nv; i++) {
+    int a = m->dof_Madr[i];
+    res[i] += M[a++] * v[i];
+    for (int j = m->dof_parentid[i]; j >= 0; j = m->dof_parentid[j], a++) { res[i] += M[a] * v[j]; res[j] += M[a] * v[i]; }
+  }
+}
+
+typedef struct primal_t {
+  const fmj_model* m; ws_t* w; int nv, n;
+  double *qacc, *Ma, *jar, *grad, *Mgrad, *search, *Mv, *Jv, *H, *D, *force, *qfc;
+  int* state;
+  double cost;
+} primal_t;
+
+/* mj_constraintUpdate for unilateral rows + the Gauss term: cost, forces, qfrc_constraint, active set */
+static void primal_update(primal_t* P) {
+  const fmj_model* m = P->m; ws_t* w = P->w; int nv = P->nv, n = P->n;
+  double cost = 0;
+  for (int e = 0; e < n; e++) {
+    if (P->jar[e] < 0) { P->force[e] = -P->D[e] * P->jar[e]; cost += 0.5 * P->D[e] * P->jar[e] * P->jar[e]; P->state[e] = 1; }
+    else { P->force[e] = 0; P->state[e] = 0; }
+  }
+  for (int i = 0; i < nv; i++) P->qfc[i] = 0;
+  for (int e = 0; e < n; e++) if (P->state[e]) for (int i = 0; i < nv; i++) P->qfc[i] += w->efc_J[(size_t)e * nv + i] * P->force[e];
+  double g = 0;
+  for (int i = 0; i < nv; i++) g += (P->Ma[i] - w->qfrc_smooth[i]) * (P->qacc[i] - w->qacc_smooth[i]);
+  P->cost = cost + 0.5 * g;
+  for (int i = 0; i < nv; i++) P->grad[i] = P->Ma[i] - w->qfrc_smooth[i] - P->qfc[i];
+  (void)m;
+}
+
+/* Mgrad = H^-1 grad, H = M + J_active' D J_active, dense Cholesky (mj_solNewton's MakeHessian / FactorizeHessian) */
+static void newton_direction(primal_t* P) {
+  const fmj_model* m = P->m; ws_t* w = P->w; int nv = P->nv, n = P->n;
+  double* H = P->H;
+  memset(H, 0, (size_t)nv * nv * sizeof(double));
+  for (int i = 0; i < nv; i++) { int a = m->dof_Madr[i]; for (int j = i; j >= 0; j = m->dof_parentid[j]) { H[i * nv + j] = H[j * nv + i] = w->qM[a++]; } }
+  for (int e = 0; e < n; e++) if (P->state[e]) {
+    const double* J = w->efc_J + (size_t)e * nv; double d = P->D[e];
+    for (int i = 0; i < nv; i++) if (J[i] != 0) for (int j = 0; j < nv; j++) H[i * nv + j] += d * J[i] * J[j];
+  }
+  for (int k = 0; k < nv; k++) {            /* in-place lower Cholesky */
+    double s = H[k * nv + k];
+    for (int c = 0; c < k; c++) s -= H[k * nv + c] * H[k * nv + c];
+    s = sqrt(s > MINVAL ? s : MINVAL);
+    H[k * nv + k] = s;
+    for (int i = k + 1; i < nv; i++) {
+      double t = H[i * nv + k];
+      for (int c = 0; c < k; c++) t -= H[i * nv + c] * H[k * nv + c];
+      H[i * nv + k] = t / s;
+    }
+  }
+  double* x = P->Mgrad;
+  for (int i = 0; i < nv; i++) { double t = P->grad[i]; for (int c = 0; c < i; c++) t -= H[i * nv + c] * x[c]; x[i] = t / H[i * nv + i]; }
+  for (int i = nv - 1; i >= 0; i--) { double t = x[i]; for (int c = i + 1; c < nv; c++) t -= H[c * nv + i] * x[c]; x[i] = t / H[i * nv + i]; }
+}
+
+typedef struct ls_pt { double alpha, cost, d0, d1; } ls_pt;
+static ls_pt ls_eval(const primal_t* P, const double* qg, double alpha) {
+  ls_pt p; p.alpha = alpha;
+  double c = qg[0] + alpha * (qg[1] + alpha * qg[2]), d0 = qg[1] + 2 * alpha * qg[2], d1 = 2 * qg[2];
+  for (int e = 0; e < P->n; e++) {
+    double x = P->jar[e] + alpha * P->Jv[e];
+    if (x < 0) { c += 0.5 * P->D[e] * x * x; d0 += P->D[e] * x * P->Jv[e]; d1 += P->D[e] * P->Jv[e] * P->Jv[e]; }
+  }
+  p.cost = c; p.d0 = d0; p.d1 = d1 > MINVAL ? d1 : MINVAL;
+  return p;
+}
+static double primal_linesearch(primal_t* P, double scale) {
+  const fmj_model* m = P->m; ws_t* w = P->w; int nv = P->nv, n = P->n;
+  mul_M_sparse(m, w->qM, P->search, P->Mv);
+  for (int e = 0; e < n; e++) P->Jv[e] = dotn(w->efc_J + (size_t)e * nv, P->search, nv);
+  double snorm = sqrt(dotn(P->search, P->search, nv));
+  if (snorm < MINVAL) return 0;
+  double qg[3] = {0, 0, 0.5 * dotn(P->search, P->Mv, nv)};
+  for (int i = 0; i < nv; i++) { qg[0] += 0.5 * (P->Ma[i] - w->qfrc_smooth[i]) * (P->qacc[i] - w->qacc_smooth[i]); qg[1] += P->search[i] * (P->Ma[i] - w->qfrc_smooth[i]); }
+  const int lsmax = m->ls_iterations > 0 ? m->ls_iterations : 50;
+  const double gtol = m->solver_tolerance * (m->ls_tolerance > 0 ? m->ls_tolerance : 0.01) * snorm / scale;
+  ls_pt p0 = ls_eval(P, qg, 0.0);
+  ls_pt p1 = ls_eval(P, qg, -p0.d0 / p0.d1);
+  if (p0.cost < p1.cost) p1 = p0;
+  if (fabs(p1.d0) < gtol) return p1.alpha;
+  int it = 0;
+  const double dir = p1.d0 < 0 ? 1.0 : -1.0;
+  ls_pt p2 = p1;
+  while (p1.d0 * dir <= -gtol && it < lsmax) {       /* one-sided Newton until phi' changes sign */
+    p2 = p1; p1 = ls_eval(P, qg, p1.alpha - p1.d0 / p1.d1); it++;
+    if (fabs(p1.d0) < gtol) return p1.alpha;
+  }
+  if (it >= lsmax || p1.d0 * dir <= 0) return p1.alpha;
+  ls_pt lo = dir > 0 ? p2 : p1, hi = dir > 0 ? p1 : p2;   /* phi'(lo) < 0 < phi'(hi): the minimiser is bracketed */
+  ls_pt best = fabs(lo.d0) < fabs(hi.d0) ? lo : hi;
+  while (it < lsmax) {
+    double a = best.alpha - best.d0 / best.d1;
+    if (!(a > lo.alpha && a < hi.alpha)) a = 0.5 * (lo.alpha + hi.alpha);
+    ls_pt p = ls_eval(P, qg, a); it++;
+    if (fabs(p.d0) < gtol) return p.alpha;
+    if (p.d0 < 0) lo = p; else hi = p;
+    best = p;
+    if (hi.alpha - lo.alpha <= 1e-16 * fabs(hi.alpha)) break;
+  }
+  return best.cost < p0.cost ? best.alpha : 0.0;
+}
+
+/* mj_solPrimal: Newton (newton = 1) or CG.  Starts from w->qacc (set by the warm start) */
+static void solve_primal(const fmj_model* m, ws_t* w, int newton) {
+  int nv = m->nv, n = w->nefc;
+  primal_t P; memset(&P, 0, sizeof P);
+  P.m = m; P.w = w; P.nv = nv; P.n = n;
+  double* buf = dalloc((size_t)9 * nv + 4 * (size_t)n + (size_t)nv * nv);
+  P.qacc = buf; P.Ma = buf + nv; P.grad = buf + 2 * nv; P.Mgrad = buf + 3 * nv; P.search = buf + 4 * nv; P.Mv = buf + 5 * nv; P.qfc = buf + 6 * nv;
+  double* oldgrad = buf + 7 * nv; double* oldMgrad = buf + 8 * nv;
+  P.jar = buf + 9 * nv; P.Jv = P.jar + n; P.D = P.Jv + n; P.force = P.D + n; P.H = P.force + n;
+  P.state = (int*)calloc(n ? n : 1, sizeof(int));
+  const double scale = 1.0 / (w->meaninertia * (nv > 1 ? nv : 1));
+  for (int e = 0; e < n; e++) P.D[e] = 1.0 / w->efc_R[e];
+  /* warm start (mj_fwdConstraint): the previous qacc unless qacc_smooth costs less */
+  double cost_ws;
+  memcpy(P.qacc, w->qacc_warmstart, nv * sizeof(double));
+  mul_M_sparse(m, w->qM, P.qacc, P.Ma);
+  for (int e = 0; e < n; e++) P.jar[e] = dotn(w->efc_J + (size_t)e * nv, P.qacc, nv) - w->efc_aref[e];
+  primal_update(&P); cost_ws = P.cost;
+  {
+    double cs = 0;
+    for (int e = 0; e < n; e++) { double x = dotn(w->efc_J + (size_t)e * nv, w->qacc_smooth, nv) - w->efc_aref[e]; if (x < 0) cs += 0.5 * P.D[e] * x * x; }
+    if (cost_ws > cs) {
+      memcpy(P.qacc, w->qacc_smooth, nv * sizeof(double));
+      mul_M_sparse(m, w->qM, P.qacc, P.Ma);
+      for (int e = 0; e < n; e++) P.jar[e] = dotn(w->efc_J + (size_t)e * nv, P.qacc, nv) - w->efc_aref[e];
+      primal_update(&P);
+    }
+  }
+  if (newton) newton_direction(&P);
+  else { memcpy(P.Mgrad, P.grad, nv * sizeof(double)); solve_ld(m, P.Mgrad, w->qLD, w->qLDiagInv); }
+  for (int i = 0; i < nv; i++) P.search[i] = -P.Mgrad[i];
+  int iter = 0;
+  while (iter < m->solver_iterations) {
+    double alpha = primal_linesearch(&P, scale);
+    if (alpha == 0) break;
+    for (int i = 0; i < nv; i++) { P.qacc[i] += alpha * P.search[i]; P.Ma[i] += alpha * P.Mv[i]; }
+    for (int e = 0; e < n; e++) P.jar[e] += alpha * P.Jv[e];
+    double oldcost = P.cost;
+    if (!newton) { memcpy(oldgrad, P.grad, nv * sizeof(double)); memcpy(oldMgrad, P.Mgrad, nv * sizeof(double)); }
+    primal_update(&P);
+    if (newton) { newton_direction(&P); for (int i = 0; i < nv; i++) P.search[i] = -P.Mgrad[i]; }
+    else {
+      memcpy(P.Mgrad, P.grad, nv * sizeof(double)); solve_ld(m, P.Mgrad, w->qLD, w->qLDiagInv);
+      double num = 0, den = dotn(oldgrad, oldMgrad, nv);
+      for (int i = 0; i < nv; i++) num += P.grad[i] * (P.Mgrad[i] - oldMgrad[i]);
+      double beta = num / fmax(MINVAL, den); if (beta < 0) beta = 0;                 /* Polak-Ribiere */
+      for (int i = 0; i < nv; i++) P.search[i] = -P.Mgrad[i] + beta * P.search[i];
+    }
+    double improvement = scale * (oldcost - P.cost), gradient = scale * sqrt(dotn(P.grad, P.grad, nv));
+    iter++;
+    if (improvement < m->solver_tolerance || gradient < m->solver_tolerance) break;
+  }
+  g_last_pgs_iterations = iter;
+  memcpy(w->qacc, P.qacc, nv * sizeof(double));
+  memcpy(w->efc_force, P.force, n * sizeof(double));
+  memcpy(w->qfrc_constraint, P.qfc, nv * sizeof(double));
+  for (int e = 0; e < n; e++) if (w->efc_type[e] == EFC_LIMIT) w->jointlimitfrc[w->efc_id[e]] += w->efc_force[e];
+  free(P.state); free(buf);
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -899,6 +1094,7 @@ static void euler(const fmj_model* m, ws_t* w, double* qpos, double* qvel) {
   else {
     memcpy(w->qH, w->qM, m->nM * sizeof(double));
     for (int i = 0; i < nv; i++) w->qH[m->dof_Madr[i]] += h * m->dof_damping[i];
+    if (g_fp32_storage) round_to_f32(w->qH, m->nM);
     factor(m, w->qH, w->qH, w->qHDiagInv);
     for (int i = 0; i < nv; i++) qacc[i] = w->qfrc_smooth[i] + w->qfrc_constraint[i];
     solve_ld(m, qacc, w->qH, w->qHDiagInv);
@@ -1227,6 +1423,50 @@ int fmjo_step(const fmj_model* m, int n_envs, int n_steps, int64_t ctrl_step_str
   }
   if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);
   free(th); free(jobs);
+  return FMJ_OK;
+}
+
+/* One mj_step per env with the solver's warm start handed in and out (teacher-forced parity runs: the caller owns the whole
+ * state, including qacc_warmstart) and the constraint problem of that step laid open.  Arrays are batch-first fp64; any
+ * output pointer may be NULL.  warmstart [n, nv]: in = qacc of the previous step, out = this step's qacc (mjData.qacc,
+ * before the implicit-damping re-solve).  counts [n, 3] = ncon, nefc, solver iterations.  efc [n, maxefc, 6] = force, b =
+ * J qacc_smooth - aref, R, aref, type (0 limit / 1 contact), id (joint / contact).  efc_AR [n, maxefc, maxefc] = J M^-1 J' +
+ * diag(R) (row stride maxefc), efc_J [n, maxefc, nv].  contact [n, max_contacts, FMJO_CONTACT_W].  maxefc =
+ * fmjo_maxefc(m).  Single-threaded. */
+int fmjo_maxefc(const fmj_model* m) { return 2 * m->njnt + 4 * (m->max_contacts > 0 ? m->max_contacts : 0); }
+int fmjo_step_tf(const fmj_model* m, int n_envs, double* qpos, double* qvel, const double* ctrl, const double* qpos_spring,
+                 const double* xfrc_applied, double* warmstart, double* sensordata, double* qacc_integrated, int32_t* counts,
+                 double* efc, double* efc_AR, double* efc_J, double* contact, int32_t* status) {
+  if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
+  ws_t* w = ws_new(m); w->meaninertia = mean_inertia(m);
+  const int nv = m->nv, nsd = nsensordata(m), me = w->maxefc, mc = m->max_contacts > 0 ? m->max_contacts : 0;
+  double* sd = dalloc(nsd);
+  for (int e = 0; e < n_envs; e++) {
+    if (warmstart) memcpy(w->qacc_warmstart, warmstart + (size_t)e * nv, nv * sizeof(double));
+    else memset(w->qacc_warmstart, 0, nv * sizeof(double));
+    int warn = step_one(m, w, qpos + (size_t)e * m->nq, qvel + (size_t)e * nv, ctrl ? ctrl + (size_t)e * m->nu : NULL,
+                        qpos_spring + (size_t)e * m->nq, xfrc_applied ? xfrc_applied + (size_t)e * m->nbody * 6 : NULL, sd);
+    if (warmstart) memcpy(warmstart + (size_t)e * nv, w->qacc, nv * sizeof(double));
+    if (sensordata) memcpy(sensordata + (size_t)e * nsd, sd, nsd * sizeof(double));
+    if (qacc_integrated) memcpy(qacc_integrated + (size_t)e * nv, w->tmpv, nv * sizeof(double));
+    if (counts) { counts[3 * e] = w->ncon; counts[3 * e + 1] = w->nefc; counts[3 * e + 2] = w->nefc ? g_last_pgs_iterations : 0; }
+    const int n = w->nefc;
+    if (efc) for (int r = 0; r < n; r++) {
+      double* o = efc + ((size_t)e * me + r) * 6;
+      o[0] = w->efc_force[r]; o[1] = dotn(w->efc_J + (size_t)r * nv, w->qacc_smooth, nv) - w->efc_aref[r]; o[2] = w->efc_R[r]; o[3] = w->efc_aref[r];
+      o[4] = w->efc_type[r]; o[5] = w->efc_id[r];
+    }
+    if (efc_J) memcpy(efc_J + (size_t)e * me * nv, w->efc_J, (size_t)n * nv * sizeof(double));
+    if (efc_AR) {
+      /* for every solver: A = J M^-1 J' + diag(R), from the factor of M of this step */
+      for (int r = 0; r < n; r++) { double* x = w->efc_MiJT + (size_t)r * nv; memcpy(x, w->efc_J + (size_t)r * nv, nv * sizeof(double)); solve_ld(m, x, w->qLD, w->qLDiagInv); }
+      for (int r = 0; r < n; r++) for (int c = 0; c < n; c++)
+        efc_AR[((size_t)e * me + r) * me + c] = dotn(w->efc_J + (size_t)r * nv, w->efc_MiJT + (size_t)c * nv, nv) + (r == c ? w->efc_R[r] : 0.0);
+    }
+    if (contact && mc) export_contacts(w, contact + (size_t)e * mc * FMJO_CONTACT_W);
+    if (status) status[e] |= warn;
+  }
+  free(sd); ws_free(w);
   return FMJ_OK;
 }
 

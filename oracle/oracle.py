@@ -36,6 +36,19 @@ def lib():
     return _lib
 
 
+class fp32_storage:
+    """Context manager: inside it the oracle rounds the stored entries of M and H = M + h B to fp32 (nothing else), see
+    fmjo_set_fp32_storage in fmj_oracle.c.  ``with oracle.fp32_storage(): floor = oracle.step(...)``."""
+
+    def __enter__(self):
+        lib().fmjo_set_fp32_storage(1)
+        return self
+
+    def __exit__(self, *exc):
+        lib().fmjo_set_fp32_storage(0)
+        return False
+
+
 def _d(a):
     return None if a is None else a.ctypes.data_as(_D)
 
@@ -71,6 +84,36 @@ def step(model, qpos, qvel, ctrl=None, qpos_spring=None, xfrc_applied=None, n_st
     assert rc == 0, rc
     out['qpos'] = qpos
     out['qvel'] = qvel
+    return out
+
+
+def step_tf(model, qpos, qvel, ctrl=None, warmstart=None, qpos_spring=None, xfrc_applied=None, want_AR=True, want_J=False):
+    """One mj_step per env with the warm start handed in and out and the step's constraint problem laid open
+    (fmjo_step_tf): teacher-forced parity runs and KKT checks.  Returns the new state plus, per env, ``ncon``, ``nefc``,
+    ``iterations``, ``efc`` [n, maxefc, 6] = (force, b, R, aref, type, id), ``AR`` [n, maxefc, maxefc] = J M^-1 J' + diag(R),
+    ``contact`` [n, max_contacts, CONTACT_W], ``warmstart`` = this step's qacc."""
+    m = model
+    c = m.as_c()
+    qpos = _c64(qpos).reshape(-1, m.nq).copy(); n = qpos.shape[0]
+    qvel = _c64(qvel).reshape(n, m.nv).copy()
+    ctrl = None if ctrl is None else _c64(ctrl).reshape(n, m.nu)
+    ws = np.zeros((n, m.nv)) if warmstart is None else _c64(warmstart).reshape(n, m.nv).copy()
+    qs = _c64(np.broadcast_to(m.qpos_spring, (n, m.nq)) if qpos_spring is None else qpos_spring).copy()
+    xf = None if xfrc_applied is None else _c64(xfrc_applied).reshape(n, m.nbody, 6)
+    f = lib().fmjo_maxefc; f.restype = ctypes.c_int
+    me = max(int(f(ctypes.byref(c))), 1)
+    mc = max(int(m.max_contacts), 1)
+    out = dict(sensordata=np.zeros((n, m.nsensordata)), qacc=np.zeros((n, m.nv)), counts=np.zeros((n, 3), np.int32),
+               efc=np.zeros((n, me, 6)), AR=np.zeros((n, me, me)) if want_AR else None, J=np.zeros((n, me, m.nv)) if want_J else None,
+               contact=np.zeros((n, mc, CONTACT_W)), status=np.zeros(n, np.int32))
+    g = lib().fmjo_step_tf
+    g.restype = ctypes.c_int
+    g.argtypes = [ctypes.c_void_p, ctypes.c_int, _D, _D, _D, _D, _D, _D, _D, _D, _I, _D, _D, _D, _D, _I]
+    rc = g(ctypes.byref(c), n, _d(qpos), _d(qvel), _d(ctrl), _d(qs), _d(xf), _d(ws), _d(out['sensordata']), _d(out['qacc']),
+           _i(out['counts']), _d(out['efc']), _d(out['AR']), _d(out['J']), _d(out['contact']), _i(out['status']))
+    assert rc == 0, rc
+    out.update(qpos=qpos, qvel=qvel, warmstart=ws, ncon=out['counts'][:, 0].copy(), nefc=out['counts'][:, 1].copy(),
+               iterations=out['counts'][:, 2].copy())
     return out
 
 

@@ -3,12 +3,9 @@ each morphology gets its own context (bucketed batching: no padding, no masks), 
 import numpy as np
 import pytest
 
+from parity_metrics import relerr as _relerr, group_relerr, qpos_groups, qvel_groups, link_row_groups
+
 pytestmark = pytest.mark.gpu
-
-
-def _relerr(a, b):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return np.abs(a - b).max()/max(np.abs(b).max(), 1e-12)
 
 
 @pytest.mark.parametrize('maker', ['eel', 'centipede'])
@@ -30,10 +27,18 @@ def test_step_parity_other_morphologies(oracle, maker):
     torch.cuda.synchronize()
     q32 = torch.as_tensor(qpos, dtype=torch.float32).numpy().astype(np.float64)
     ref1 = oracle.step(m, q32, qvel, ctrl=tape_t[:1].cpu().numpy().astype(np.float64), n_steps=1, ctrl_step_stride=n*m.nu)
-    # the first step starts from rest with a ctrl jump (qacc ~ 5e4 rad/s^2); the long, light chains of these
-    # morphologies amplify fp32 rounding of M in the solve more than the salamander does -> 2e-3 on qvel
-    for k, tol in (('xpos', 2e-6), ('xquat', 2e-6), ('sensordata', 5e-5), ('qvel', 2e-3), ('qpos', 2e-4)):
+    # the first step starts from rest with a ctrl jump (qacc ~ 5e4 rad/s^2).  The joint-space inertia of these long, light
+    # chains is ill-conditioned (scaled condition number ~1e5): storing it in fp32 alone moves the solution by 1e-4 .. 5e-4 of
+    # its maximum (oracle.fp32_storage: the fp64 oracle with M / H rounded to fp32, nothing else).  The velocity bound is
+    # stated against that floor, per component, instead of a fitted number.
+    with oracle.fp32_storage():
+        floor1 = oracle.step(m, q32, qvel, ctrl=tape_t[:1].cpu().numpy().astype(np.float64), n_steps=1, ctrl_step_stride=n*m.nu)
+    for k, tol in (('xpos', 2e-6), ('xquat', 2e-6), ('sensordata', 5e-5)):
         assert _relerr(getattr(d, k).cpu().numpy(), ref1[k]) < tol, (maker, k, _relerr(getattr(d, k).cpu().numpy(), ref1[k]))
+    for k, groups in (('qvel', qvel_groups(m)), ('qpos', qpos_groups(m))):
+        err = group_relerr(getattr(d, k).cpu().numpy(), ref1[k], groups); fl = group_relerr(floor1[k], ref1[k], groups)
+        print(maker, k, 'first step: per-component err', err, 'fp32-storage floor', fl)
+        assert err < 6*fl + 1e-6, (maker, k, err, fl)
     phys.step(T - 1, ctrl_tape=tape_t[1:].contiguous())
     torch.cuda.synchronize()
     ref = oracle.step(m, q32, qvel, ctrl=tape_t.cpu().numpy().astype(np.float64), n_steps=T, ctrl_step_stride=n*m.nu, n_threads=8)
@@ -90,19 +95,25 @@ def test_mixed_batch_bucketed(oracle):
     T = 40
     sims = [_bucket_sim(maker, n, T, T) for maker, n in (('eel', 24), ('centipede', 8))]
     refs = [_bucket_oracle(oracle, sim, m, T, T, list(range(sim.physics.n_envs))) for sim, m in sims]
+    with oracle.fp32_storage():       # the floor: the same fp64 loop with its stored M / H rounded to fp32 and nothing else
+        floors = [_bucket_oracle(oracle, sim, m, T, T, list(range(sim.physics.n_envs))) for sim, m in sims]
     for sim, _ in sims:
         sim.run(fused=True)
     torch.cuda.synchronize()
-    for (sim, m), ref in zip(sims, refs):
+    for (sim, m), ref, flo in zip(sims, refs, floors):
         assert int(sim.physics.data.status.abs().sum()) == 0
         sens = sim.task.data.sensors
-        errs = dict(qpos=_relerr(sim.physics.data.qpos.cpu().numpy(), ref['qpos']), links=_relerr(sens.links.array.cpu().numpy(), ref['links']),
-                    xfrc=_relerr(sens.xfrc.array.cpu().numpy(), ref['xfrc']), joints=_relerr(sens.joints.array.cpu().numpy(), ref['joints']))
-        print(m.name, errs)
-        # link rows carry velocities, which start from rest with a ctrl jump (the first step's qvel is good to 2e-3 on these
-        # long light chains, see test_step_parity_other_morphologies); qpos itself stays within the 1e-4 target
-        # (centipede link rows: 1.8e-3 ... 2.0e-3 depending on the summation order of the build)
-        assert errs['qpos'] < 1e-4 and errs['links'] < 3e-3 and errs['xfrc'] < 2e-3 and errs['joints'] < 3e-3, (m.name, errs)
+        got = dict(qpos=sim.physics.data.qpos.cpu().numpy(), links=sens.links.array.cpu().numpy(), xfrc=sens.xfrc.array.cpu().numpy(),
+                   joints=sens.joints.array.cpu().numpy())
+        groups = dict(qpos=qpos_groups(m), links=link_row_groups(), xfrc=[slice(0, 3), slice(3, 6)], joints=[slice(0, 1), slice(1, 2), slice(8, 9)])
+        errs = {k: group_relerr(got[k], ref[k], groups[k]) for k in got}
+        fls = {k: group_relerr(flo[k], ref[k], groups[k]) for k in got}
+        print(m.name, 'err', errs, 'fp32-storage floor', fls)
+        # the rows carry velocities and forces that start from rest with a ctrl jump; on these long light chains they are bounded
+        # by what fp32 storage of the inertia matrix alone costs over the same 40 steps (per component), qpos by the 1e-4 target
+        assert _relerr(got['qpos'], ref['qpos']) < 1e-4
+        for k in got:
+            assert errs[k] < 6*fls[k] + 1e-6, (m.name, k, errs[k], fls[k])
         assert np.abs(sens.links.array.cpu().numpy()[-1, :, :, 14:17]).max() > 1e-3      # it swims
     # a bucket run alone gives bitwise the same rows
     alone, _ = _bucket_sim('eel', 24, T, T)

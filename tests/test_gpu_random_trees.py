@@ -6,6 +6,8 @@ import pytest
 
 pytestmark = pytest.mark.gpu
 
+FMJ_WARN_CONTACTFULL = 8      # include/fmj.h (FMJ_WARN_BADQACC is 4: a frozen env must fail these tests)
+
 
 def random_tree(seed, contacts=False, meshes=False):
     from farms_mujoco_amd.model import ModelBuilder, euler2quat, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_PLANE
@@ -110,8 +112,14 @@ def test_random_tree_vs_oracle(oracle, seed, two_per_wave, monkeypatch):
     def err(k):
         a = r64(getattr(d, k)); bb = ref[k]
         return np.abs(a - bb).max()/max(np.abs(bb).max(), 1e-9)
-    for k, tol in (('xpos', 5e-6), ('xquat', 5e-6), ('xipos', 5e-6), ('sensordata', 1e-4), ('qvel', 5e-4), ('qpos', 5e-6)):
+    for k, tol in (('xpos', 5e-6), ('xquat', 5e-6), ('xipos', 5e-6), ('sensordata', 1e-4), ('qpos', 5e-6)):
         assert err(k) < tol, (seed, m.nbody, m.nv, k, err(k))
+    # the velocity comes out of the (M + hB) solve: bounded by a small multiple of what fp32 storage of that matrix alone costs
+    # on this tree (oracle.fp32_storage), plus the fp32 rounding of a well-conditioned solve
+    with oracle.fp32_storage():
+        floor = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None, qpos_spring=s32, xfrc_applied=x32)
+    fl = np.abs(floor['qvel'] - ref['qvel']).max()/max(np.abs(ref['qvel']).max(), 1e-9)
+    assert err('qvel') < 6*fl + 2e-6, (seed, m.nbody, m.nv, 'qvel', err('qvel'), fl)
     phys.step(49)
     torch.cuda.synchronize()
     ref = oracle.step(m, q32, v32, ctrl=c32 if m.nu else None, qpos_spring=s32, xfrc_applied=x32, n_steps=50)
@@ -147,7 +155,7 @@ def test_random_tree_with_limits_and_contacts(oracle, seed):
     q32, v32, c32 = r64(d.qpos), r64(d.qvel), r64(d.ctrl)
     phys.step(1)
     torch.cuda.synchronize()
-    assert int((d.status & ~4).abs().sum()) == 0                       # CONTACTFULL (bit 4) may be raised by both sides
+    assert int((d.status & ~FMJ_WARN_CONTACTFULL).abs().sum()) == 0     # a truncated contact list (both sides truncate alike) is the only bit allowed
     fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=c32[e] if m.nu else None) for e in range(n)]
     ncon_ref = np.array([fd['ncon'] for fd in fds])
     assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref), (d.ncon.cpu().numpy(), ncon_ref)
@@ -192,7 +200,7 @@ def test_random_tree_with_mesh_geoms(oracle, seed):
     q32, v32 = r64(d.qpos), r64(d.qvel)
     phys.step(1)
     torch.cuda.synchronize()
-    assert int((d.status & ~4).abs().sum()) == 0
+    assert int((d.status & ~FMJ_WARN_CONTACTFULL).abs().sum()) == 0
     fds = [oracle.forward_debug(m, q32[e], v32[e], ctrl=np.zeros(m.nu) if m.nu else None) for e in range(n)]
     ncon_ref = np.array([fd['ncon'] for fd in fds])
     assert np.array_equal(d.ncon.cpu().numpy(), ncon_ref), (d.ncon.cpu().numpy(), ncon_ref)

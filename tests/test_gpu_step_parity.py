@@ -6,6 +6,8 @@ relative error after 1000 steps (fp64 -> fp32).
 import numpy as np
 import pytest
 
+from parity_metrics import relerr as _relerr, group_relerr, qpos_groups, qvel_groups
+
 pytestmark = pytest.mark.gpu
 
 
@@ -25,11 +27,6 @@ def _rand_state(m, n, seed, qscale=0.3, vscale=0.5):
     return qpos, qvel, ctrl
 
 
-def _relerr(a, b):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return np.abs(a - b).max()/max(np.abs(b).max(), 1e-12)
-
-
 @pytest.fixture(scope='module')
 def sal():
     from farms_mujoco_amd.model import salamander33
@@ -43,9 +40,12 @@ def _gpu_physics(m, n):
 
 
 def test_single_step_all_fields(sal, oracle):
-    """One mj_step from random states. Kinematic fields and sensors agree to fp32 rounding (2e-6 ..
-    2e-5 of the field maximum); qvel/qacc to 1e-4: the (M + hB) solve of the light, stiffly actuated
-    limb chains amplifies fp32 rounding of the inertia entries."""
+    """One mj_step from random states.  Kinematic fields and sensors agree to fp32 rounding (2e-6 .. 2e-5 of the field
+    maximum).  qvel / qacc come out of the (M + hB) solve, and that matrix is ill-conditioned (light, stiffly actuated limb
+    chains on a heavy trunk: scaled condition number 3e4): merely STORING it in fp32 moves the solution by ~1e-5 of its
+    maximum, whatever computes it.  The bound is therefore stated against that floor - the fp64 oracle with its stored M / H
+    rounded to fp32 and nothing else (oracle.fp32_storage) - per component (parity_metrics.group_relerr), not as a fitted
+    number: the HIP step stays within 6x of it (measured 2 - 3x)."""
     m, n = sal, 64
     phys, torch = _gpu_physics(m, n)
     qpos, qvel, ctrl = _rand_state(m, n, 1)
@@ -54,14 +54,24 @@ def test_single_step_all_fields(sal, oracle):
     d = phys.data
     d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
     d.ctrl[:] = torch.as_tensor(ctrl, dtype=torch.float32); d.xfrc_applied[:] = torch.as_tensor(xf, dtype=torch.float32)
+    r64 = lambda t: t.cpu().numpy().astype(np.float64)
+    q32, v32, c32, x32 = r64(d.qpos), r64(d.qvel), r64(d.ctrl), r64(d.xfrc_applied)     # the fp32-rounded inputs are THE inputs
     phys.step(1)
     torch.cuda.synchronize()
-    ref = oracle.step(m, qpos, qvel, ctrl=ctrl, xfrc_applied=xf)
+    ref = oracle.step(m, q32, v32, ctrl=c32, xfrc_applied=x32)
+    with oracle.fp32_storage():
+        floor = oracle.step(m, q32, v32, ctrl=c32, xfrc_applied=x32)
     assert int(d.status.abs().sum()) == 0
-    for name, tol in (('qpos', 2e-6), ('qvel', 1e-4), ('xpos', 2e-6), ('xquat', 2e-6), ('xipos', 2e-6),
-                      ('sensordata', 2e-5), ('qacc', 1e-4)):
+    for name, tol in (('xpos', 2e-6), ('xquat', 2e-6), ('xipos', 2e-6), ('sensordata', 2e-5)):
         err = _relerr(getattr(d, name).cpu().numpy(), ref[name])
         assert err < tol, (name, err)
+    for name in ('qpos', 'qvel', 'qacc'):
+        groups = qpos_groups(m) if name == 'qpos' else qvel_groups(m)
+        err = group_relerr(r64(getattr(d, name)), ref[name], groups)
+        fl = group_relerr(floor[name], ref[name], groups) + (1e-6 if name == 'qpos' else 0.0)     # + the fp32 rounding of q itself
+        print(name, 'per-component err', err, 'fp32-storage floor', fl)
+        assert err < 6*fl, (name, err, fl)
+        assert _relerr(r64(getattr(d, name)), ref[name]) < 1e-4        # and the old whole-tensor statement still holds (qpos: 2e-6)
 
 
 def test_forward_only_matches_oracle_derived(sal, oracle):
@@ -107,8 +117,15 @@ def test_thousand_steps_qpos(sal, oracle):
     ref = oracle.step(m, qpos32, qvel32, ctrl=tape32, n_steps=T, ctrl_step_stride=n*m.nu, n_threads=8)
     assert int(d.status.abs().sum()) == 0
     err = _relerr(d.qpos.cpu().numpy(), ref['qpos'])
-    print('qpos rel err after 1000 steps:', err)
-    assert err < 1e-4, err
+    # per component (root position, quaternion, joint angles each against their own scale): small joint angles are the hardest
+    # (6.5e-6 rad on angles of 0.02 .. 0.3 rad); stated against the same 1000 steps with M / H merely stored in fp32
+    with oracle.fp32_storage():
+        floor = oracle.step(m, qpos32, qvel32, ctrl=tape32, n_steps=T, ctrl_step_stride=n*m.nu, n_threads=8)
+    gerr = group_relerr(d.qpos.cpu().numpy(), ref['qpos'], qpos_groups(m))
+    gfl = group_relerr(floor['qpos'], ref['qpos'], qpos_groups(m))
+    print('qpos rel err after 1000 steps:', err, 'per component:', gerr, 'fp32-storage floor per component:', gfl)
+    assert err < 1e-4, err                               # the north-star statement (whole-vector relative error)
+    assert gerr < 6*gfl and gerr < 5e-4, (gerr, gfl)
 
 
 def test_batch_invariance_bitwise(sal):
