@@ -30,11 +30,11 @@ def algorithmic_bytes_per_env_step(m, sim=None, workload='swim', sims=None):
     def one(m_, sim_):
         n_links = m_.nbody - 1
         n_joints = m_.n_sensor_joints
-        ns = len(m_.swimming) if workload != 'walk' else 0
+        ns = len(m_.swimming) if not workload.startswith('walk') else 0
         core = 4*(m_.nq + m_.nv + m_.nu) + 4*(m_.nq + m_.nv)
         log = 4*(20*n_links + 4*n_joints + 6*ns)
         cons = 0
-        if workload == 'walk':
+        if workload.startswith('walk'):
             n_cs = len(sim_.task.data.sensors.contacts.names) if sim_ is not None else 0
             cons = 8*m_.nv + 4*12*n_cs
         return core, log, cons
@@ -56,15 +56,16 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
     from farms_mujoco_amd.control import WaveController
     from farms_mujoco_amd.simulation.simulation import Simulation
     from farms_mujoco_amd.data import AnimatData
-    if workload == 'walk':
-        m = mm.salamander33(contacts=True, limits=True, spawn_z=0.045)
+    if workload.startswith('walk'):       # walk_pairs / walk_hfield / walk_mesh: the same walker with self-collision pairs, on a heightfield, on mesh feet
+        m = mm.salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=workload == 'walk_pairs',
+                            terrain='hfield' if workload == 'walk_hfield' else 'plane', mesh_feet=workload == 'walk_mesh')
     else:
         m = getattr(mm, morphology)()
     qpos, qvel, psi = mm.synthetic_batch(m, n_envs, seed=0, env_offset=env_offset)
     opts = SimulationOptions(timestep=m.timestep, n_iterations=n_iterations)
     ctl = WaveController(m, psi, device=device)
     kw = {}
-    if workload == 'walk':
+    if workload.startswith('walk'):
         arena = ArenaOptions(water=WaterOptions(height=None, drag=False), ground_height=0.0)
         amp, lag = mm.trot_controller_params(m)
         ctl.amplitude = torch.as_tensor(amp, dtype=torch.float32, device=device)
@@ -83,14 +84,31 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
     return sim, m, (qpos, qvel, psi)
 
 
+def usable_cores():
+    """Host cores this process may actually use: its affinity mask, capped by the cgroup CPU quota when there is one (a
+    container that sees every core of the host but is granted a share of them)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:                                                   # cgroup v2: "<quota> <period>" or "max <period>"
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if q != 'max':
+            n = min(n, max(1, int(int(q)/int(per))))
+    except Exception:
+        try:                                               # cgroup v1
+            q = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read()); per = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if q > 0:
+                n = min(n, max(1, q//per))
+        except Exception:
+            pass
+    return n
+
+
 def cpu_baseline(m, sim, target_seconds=12.0):
     """The fp64 CPU oracle (C restatement, NOT MuJoCo: the reference's mj_step loop cannot run here, see
     BASELINE.md §2) timed on this box's host cores on a bounded sample of the same workload."""
     import subprocess
     from oracle import oracle
     from farms_mujoco_amd.model import synthetic_batch
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    cores = min(cores, 16) if os.environ.get('GRAFT_REPO_ROOT') else cores     # a 1-GPU box grants a 16-core share
+    cores = usable_cores()
     n_envs = 64*cores                                                          # >= 64 envs per thread
     so = os.path.join(ROOT, 'oracle', '_build', 'libfmj_oracle_native.so')
     try:
@@ -182,13 +200,16 @@ def main():
     ap.add_argument('--warmup', type=int, default=3000)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
     ap.add_argument('--chunk', type=int, default=100, help='steps per fused launch (= ring-buffer length)')
-    ap.add_argument('--min-seconds', type=float, default=0.25,
+    ap.add_argument('--min-seconds', type=float, default=2.0,
                     help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the short walk / mixed measurements appended to the swim line')
-    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed'],
-                    help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede')
-    ap.add_argument('--dist-backend', default='nccl', help="'gloo' + --same-device rehearses the N>1 path on a 1-GPU box")
+    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh'],
+                    help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede; walk_pairs / '
+                         'walk_hfield / walk_mesh = the walker with self-collision pairs / on a heightfield / on convex-mesh feet')
+    ap.add_argument('--dist-backend', default='gloo',
+                    help="process group of the N > 1 run: it carries a barrier and two scalar reductions, no data, so gloo on CPU tensors "
+                         "is the default (north_star: no RCCL); 'nccl' remains selectable")
     ap.add_argument('--same-device', action='store_true', help='all ranks use cuda:0 (rehearsal only)')
     args = ap.parse_args()
 
@@ -278,27 +299,38 @@ def main():
         # HBM bytes and issue shares from the PMC passes (rocprofv3 cannot run inside this process): the committed summary
         # of the same workload, per env-step, produced as DESIGN.md section 5 describes (scripts/pmc_summary.py)
         traffic, binding, src = None, None, None
+        from farms_mujoco_amd import _lib as fmj_lib
+        build = fmj_lib.build_id()
+        stale = None
         try:
             for tr in json.load(open(os.path.join(ROOT, 'profiles', 'latest_traffic.json'))):
                 if tr['workload'] == args.workload and tr['envs'] == n_envs:
+                    if tr.get('build_id') != build:        # counters of another build of the kernels are not this run's traffic
+                        stale = f"{tr.get('source')} was taken on build {tr.get('build_id')}, this is build {build}"
+                        continue
                     traffic = (tr['fetch_bytes_per_env_step'] + tr['write_bytes_per_env_step'])*n_envs*chunk
                     binding = tr.get('binding')
                     src = tr.get('source')
         except Exception:
             pass
-        names = {'swim': 'salamander swim (~40 DoF)', 'walk': 'salamander walk on plane (PGS contacts)', 'mixed': 'eel + centipede swim (bucketed)'}
+        names = {'swim': 'salamander swim (~40 DoF)', 'walk': 'salamander walk on plane (PGS contacts)', 'mixed': 'eel + centipede swim (bucketed)',
+                 'walk_pairs': 'salamander walk on plane with self-collision pairs', 'walk_hfield': 'salamander walk on a heightfield',
+                 'walk_mesh': 'salamander walk on convex-mesh feet'}
         out = {
             'metric': f'env-steps/sec, {names[args.workload]} \u00d7{n_envs} envs, 1/2/4/8 MI355X',
             'value': n_envs*world*K*R/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'repeats': R, 'steps_timed': K*R, 'timed_region_s': dt,
             'ms_per_step': dt/(K*R)*1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f32', 'data': 'synthetic',
+            'dtype': 'f32', 'data': 'synthetic', 'build_id': build,
             'config': {'workload': {'swim': f'BASELINE configs[1]: {n_envs}x salamander-33 swimming per GPU (nbody={m.nbody}, '
                                             f'nv={m.nv}, nu={m.nu}), drag+buoyancy, no contact, h=1e-3, travelling-wave position '
                                             f'control, sensor rows logged every step; synthetic model per SURVEY Appendix D except limb '
                                             f'kp 0.1 / inertia 1e-6 (Appendix D values are unstable at h=1e-3: DESIGN 3)',
                                     'walk': f'BASELINE configs[3]: {n_envs}x salamander-33 walking on a plane per GPU, joint limits + '
                                             f'sphere/capsule contacts, pyramidal cone, PGS <= 50 sweeps, link/joint/contact rows logged',
+                                    'walk_pairs': f'{n_envs}x salamander-33 walking on a plane, + 16 explicit self-collision pairs (feet / trunk / feet)',
+                                    'walk_hfield': f'{n_envs}x salamander-33 walking on a 65 x 65 heightfield (+-5 mm)',
+                                    'walk_mesh': f'{n_envs}x salamander-33 walking on a plane on convex-mesh feet (12-vertex hulls)',
                                     'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
                                              f'GPU, one bucket (launch, HIP stream) per morphology, launched side by side'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',
@@ -307,8 +339,9 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'frac_log_only': b['log']*n_envs*chunk/avg_launch_s/1e9/HBM_PEAK_GBS,
-                         'traffic_note': 'HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
-                                         f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}',
+                         'traffic_note': ('HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
+                                          f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}') if traffic is not None else
+                                         (f'null: {stale}' if stale else 'null: no PMC summary of this workload / batch size under profiles/'),
                          'kernel': ('fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)' if info['threads_per_env'] == 32
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,

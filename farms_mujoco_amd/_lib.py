@@ -98,6 +98,18 @@ SYMBOLS = {
     'fmj_cpg_tape': (ctypes.c_int, [_VP, ctypes.c_int32, ctypes.c_int32, ctypes.c_double, _VP, _VP, _VP, _VP, _VP, _VP]),
 }
 
+def build_id() -> str:
+    """sha1 (16 hex digits) of the sources libfmj_hip.so is built from (csrc/*.hip, csrc/*.inc, include/fmj.h): stamps measurements
+    (bench.py, profiles/latest_traffic.json) so that counters taken on another build of the kernels are not reported as current."""
+    import hashlib
+    h = hashlib.sha1()
+    for f in sorted(os.listdir(CSRC)):
+        if f.endswith('.hip') or f.endswith('.inc'):
+            h.update(f.encode()); h.update(open(os.path.join(CSRC, f), 'rb').read())
+    h.update(open(HEADER, 'rb').read())
+    return h.hexdigest()[:16]
+
+
 _lib = None
 ABI_VERSION = 4         # FMJ_ABI_VERSION of include/fmj.h
 

@@ -663,10 +663,14 @@ def _capsule_inertia(mass, radius, length):
 
 
 def salamander33(contacts: bool = False, limits: bool = False, full_actuators: bool = True,
-                 timestep: float = 1e-3, spawn_z: float = -0.1) -> Model:
+                 timestep: float = 1e-3, spawn_z: float = -0.1, self_collisions: bool = False, terrain: str = 'plane',
+                 mesh_feet: bool = False) -> Model:
     """salamander-33: free root + 11 spine hinges (z) + 4 legs x 4 hinges.
 
     nbody=29, njnt=28, nq=34, nv=33; ``full_actuators`` -> nu=81 (mjcf.py:819-854 triple), else nu=27.
+    With ``contacts``: ``self_collisions`` adds explicit foot / trunk and foot / foot pairs (morphology.self_collisions,
+    reference mjcf.py:1012-1033), ``terrain='hfield'`` replaces the plane by a gently rolling heightfield (reference
+    task.py:108-123), ``mesh_feet`` replaces the foot spheres by small convex meshes (reference mjcf.py:270-413).
     """
     b = ModelBuilder('salamander33', timestep=timestep)
     n_spine, L = 12, 0.08
@@ -716,11 +720,29 @@ def salamander33(contacts: bool = False, limits: bool = False, full_actuators: b
             b.set_swimming(name, density=1000.0,
                            drag_coefficients=[[-0.3, -0.3, -0.003], [-1e-5, -1e-5, -1e-6]],
                            height=0.5*(fl/2 + fr))
-            if contacts:
+            if contacts and mesh_feet:      # an icosahedron of the sphere's radius: 12 hull vertices
+                g = (1 + 5**0.5)/2
+                ico = np.array([(0, s1, s2*g) for s1 in (-1, 1) for s2 in (-1, 1)] + [(s1, s2*g, 0) for s1 in (-1, 1) for s2 in (-1, 1)] +
+                               [(s2*g, 0, s1) for s1 in (-1, 1) for s2 in (-1, 1)], float)
+                b.add_mesh_geom(name, ico*(fr/np.linalg.norm(ico[0])), pos=(0, 0, -fl), friction=(1.0, 0, 0))
+            elif contacts:
                 b.add_geom(name, GEOM_SPHERE, (fr,), pos=(0, 0, -fl), friction=(1.0, 0, 0))
     if contacts:
-        b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))     # arena friction 0 (mjcf.py:1202)
+        if terrain == 'hfield':             # rolling ground, +-5 mm over a 4 m x 4 m patch of 65 x 65 samples (elevation = data * 0.01)
+            gy, gx = np.meshgrid(np.linspace(-2, 2, 65), np.linspace(-2, 2, 65), indexing='ij')
+            b.add_hfield(0.5*np.sin(7.0*gx)*np.cos(5.0*gy), (2.0, 2.0, 0.01, 0.1), friction=(0, 0, 0))
+        else:
+            b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))     # arena friction 0 (mjcf.py:1202)
         b.options['max_contacts'] = 32
+        if self_collisions:                 # feet against the trunk segments they can reach and against each other
+            assert not mesh_feet, 'explicit pairs need sphere / capsule geoms'
+            for tag, trunk in (('front', (0, 2, 3)), ('hind', (4, 6, 7))):
+                for sname in ('L', 'R'):
+                    for t in trunk:
+                        b.add_contact_pair(f'leg_{tag}_{sname}_3', f'body_{t}')
+                b.add_contact_pair(f'leg_{tag}_L_3', f'leg_{tag}_R_3')
+            for sname in ('L', 'R'):
+                b.add_contact_pair(f'leg_front_{sname}_3', f'leg_hind_{sname}_3')
     for jn in [f'joint_body_{i}' for i in range(1, n_spine)] + [
             f'joint_leg_{t}_{s}_{k}' for t in ('front', 'hind') for s in ('L', 'R') for k in range(4)]:
         kp = 1.0 if jn.startswith('joint_body_') else 0.1

@@ -170,7 +170,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                            height=height if height is not None else 0.5*rbound)          # drag.pyx:364-372
         if use_collisions:
             fr = list(lo.friction) if lo is not None and getattr(lo, 'friction', None) is not None else list(friction)
-            for col in link.collisions:                     # :245-267 (margin 0, condim 3)
+            for ci, col in enumerate(link.collisions):      # :245-267 (margin 0, condim 3)
                 g = col.geometry
                 gkw = dict(pos=[p*units.meters for p in col.pose[:3]], quat=euler2mjcquat(col.pose[3:]), friction=fr,
                            solref=solref if solref is not None else DEFAULT_SOLREF,
@@ -184,7 +184,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
                 elif g.kind == 'box':                   # SDF box size = full edge lengths, MuJoCo box size = half extents
                     b.add_geom(link.name, GEOM_BOX, tuple(0.5*x*units.meters for x in g.size[:3]), **gkw)
                 elif g.kind == 'mesh':                  # :270-413: a MuJoCo mesh geom collides as its convex hull
-                    b.add_mesh_geom(link.name, mesh_of(link.collisions.index(col))*units.meters, **gkw)
+                    b.add_mesh_geom(link.name, mesh_of(ci)*units.meters, **gkw)     # by position: collisions may share a name
                 else:
                     raise NotImplementedError(f'collision shape {g.kind!r} of link {link.name} is outside the HIP subset '
                                               '(sphere / capsule / cylinder / box / convex mesh against planes and a heightfield)')
@@ -255,14 +255,20 @@ def arena_heightfield(arena_options, units=None):
             img = img[:, :, 0] if img.ndim == 3 else img[:, :]                      # RGB vs grey (:492)
             vmin, vmax = np.iinfo(img.dtype).min, np.iinfo(img.dtype).max
             data = np.flip((img.astype(float) - vmin)/(vmax - vmin), axis=0)       # normalise, Cartesian rows (:493-495)
-            spawn = getattr(getattr(arena_options, 'spawn', None), 'pose', [0]*6)
-            pos = np.array(spawn[:3], float) + np.array(link.pose[:3]) + np.array(col.pose[:3])
+            # the reference OVERWRITES the arena base link's pose with arena_options.spawn.pose (+ ground_height), :1207-1211; the
+            # collision keeps its own pose under that body: world pose = spawn pose o collision pose (rotations composed, not
+            # Euler angles added; the SDF link pose of the base link plays no part)
+            spawn = np.array(getattr(getattr(arena_options, 'spawn', None), 'pose', [0]*6), float)
+            base_pos = spawn[:3].copy()
             if getattr(arena_options, 'ground_height', None) is not None:
-                pos[2] += arena_options.ground_height                             # :1210-1211
+                base_pos[2] += arena_options.ground_height                        # :1210-1211
+            base_quat = euler2mjcquat(spawn[3:])
+            from ..model import quat_mul, quat2mat
+            pos = base_pos + quat2mat(base_quat) @ np.array(col.pose[:3], float)
             return dict(data=2*(data - 0.5),                                        # task.py:115
                         size=(0.5*g.size[0]*units.meters, 0.5*g.size[1]*units.meters, 0.5*g.size[2]*units.meters,
                               g.size[2]*units.meters),                              # :505-510
-                        pos=pos*units.meters, quat=euler2mjcquat(np.array(spawn[3:], float) + np.array(link.pose[3:])),
+                        pos=pos*units.meters, quat=quat_mul(base_quat, euler2mjcquat(col.pose[3:])),
                         image=data)
     return None
 

@@ -104,6 +104,10 @@ def drag_forces(iteration, data_links, links_index, data_xfrc, xfrc_index, coeff
     (False where the link is above the surface and its xfrc row was left untouched, drag.pyx:192-194)."""
     links = data_links.array if hasattr(data_links, 'array') else data_links
     xfrc = data_xfrc.array if hasattr(data_xfrc, 'array') else data_xfrc
+    for name, t in (('links', links), ('xfrc', xfrc)):     # the kernel reads raw fp32 rows with a unit column stride
+        if t.dtype != torch.float32 or t.stride(-1) != 1 or not t.is_cuda:
+            raise TypeError(f'drag_forces: data_{name}.array must be a float32 device tensor with a unit last stride '
+                            f'(got {t.dtype}, stride {tuple(t.stride())}, {t.device})')
     lrow = links[iteration, :, links_index]           # [n_envs, 20] view, env stride = links.stride(1)
     xrow = xfrc[iteration, :, xfrc_index]
     n_envs = lrow.shape[0]

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, '_build', 'libfmj_oracle.so')
+_SO = os.environ.get('FMJ_ORACLE_SO') or os.path.join(_HERE, '_build', 'libfmj_oracle.so')   # FMJ_ORACLE_SO: the sanitizer build (make asan)
 _lib = None
 
 _D = ctypes.POINTER(ctypes.c_double)
@@ -23,7 +23,7 @@ def build(force=False):
     hdr = os.path.join(_HERE, '..', 'include', 'fmj.h')
     if (force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src)
             or os.path.getmtime(_SO) < os.path.getmtime(hdr)):
-        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'])
+        subprocess.check_call(['make', '-C', _HERE, '-s', '-B'] + (['asan'] if _SO.endswith('_asan.so') else []))
     return _SO
 
 

@@ -61,6 +61,6 @@ json.dump(bench, open(f'profiles/{tag}_bench.json', 'w'))
 path = 'profiles/latest_traffic.json'
 cur = [e for e in (json.load(open(path)) if os.path.exists(path) else []) if not (e['workload'] == workload and e['envs'] == envs)]
 cur.append(dict(workload=workload, envs=envs, fetch_bytes_per_env_step=fb/(envs*steps), write_bytes_per_env_step=wb/(envs*steps),
-                binding=binding, source=f'profiles/{tag}_pmc_summary.txt'))
+                binding=binding, source=f'profiles/{tag}_pmc_summary.txt', build_id=bench.get('build_id')))
 json.dump(cur, open(path, 'w'), indent=1)
 print('\n'.join(out))

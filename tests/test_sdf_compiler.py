@@ -295,3 +295,38 @@ def test_mesh_collision_from_obj_and_stl(tmp_path):
     assert np.allclose(m.geom_pos[g], [0.01, 0, 0]) and abs(m.geom_size[g][2] - 0.1) < 1e-12      # bounding radius about the geom origin
     xml = model2mjcf_xml(m)
     assert '<mesh name="mesh_%d"' % g in xml and 'type="mesh"' in xml
+
+
+def test_arena_pose_is_the_spawn_pose_composed_with_the_collision_pose(sdf_path, tmp_path):
+    """The reference overwrites the arena base link's pose with arena_options.spawn.pose (+ ground_height) and keeps the
+    collision's own pose under that body (mjcf.py:1207-1211): a rotated, offset arena puts the heightfield at
+    spawn o collision - rotations composed, the SDF link pose of the base link ignored."""
+    from farms_mujoco_amd.io.png import imwrite_gray
+    from farms_mujoco_amd.model import GEOM_HFIELD, quat_mul, quat2mat, euler2quat
+    imwrite_gray(str(tmp_path/'terrain.png'), np.zeros((4, 4), np.uint16))
+    (tmp_path/'arena.sdf').write_text(ARENA_SDF.replace('<pose>0 0 0 0 0 0</pose>\n      <collision', '<pose>5 5 5 1 1 1</pose>\n      <collision')
+                                      .replace('<collision name="terrain_col"><pose>0 0 0 0 0 0</pose>', '<collision name="terrain_col"><pose>0.3 0 0.1 0 0 0.4</pose>'))
+    spawn = [0.1, -0.2, 0.0, 0.0, 0.3, 1.2]
+    arena = ArenaOptions(sdf=str(tmp_path/'arena.sdf'), ground_height=0.05, spawn_pose=spawn)
+    m = setup_model(SimulationOptions(timestep=1e-3), _options(sdf_path), arena)
+    g = int(np.nonzero(m.geom_type == GEOM_HFIELD)[0][0])
+    bq = euler2quat(spawn[3:])
+    assert np.allclose(m.geom_pos[g], np.array([0.1, -0.2, 0.05]) + quat2mat(bq) @ np.array([0.3, 0, 0.1]))
+    want_q = quat_mul(bq, euler2quat([0, 0, 0.4]))
+    assert min(np.abs(m.geom_quat[g] - want_q).max(), np.abs(m.geom_quat[g] + want_q).max()) < 1e-12
+
+
+def test_two_collisions_with_one_name_sphere_then_mesh(tmp_path):
+    """A link whose collisions share a name (the SDF reader's default `<link>_collision`) with the mesh not first: the mesh is
+    found by its position in the list, not by comparing Collision objects (which hold arrays)."""
+    from farms_mujoco_amd.io.sdf import ModelSDF
+    from farms_mujoco_amd.simulation.mjcf import sdf2model
+    (tmp_path / 'tet.obj').write_text('v 0 0 0\nv 1 0 0\nv 0 1 0\nv 0 0 1\nf 1 3 2\nf 1 2 4\nf 1 4 3\nf 2 3 4\n')
+    (tmp_path / 'm.sdf').write_text('''<sdf version="1.6"><model name="m">
+      <link name="base"><pose>0 0 0.2 0 0 0</pose>
+        <inertial><mass>0.3</mass><inertia><ixx>1e-4</ixx><iyy>1e-4</iyy><izz>1e-4</izz></inertia></inertial>
+        <collision name="same"><pose>0 0 0 0 0 0</pose><geometry><sphere><radius>0.02</radius></sphere></geometry></collision>
+        <collision name="same"><pose>0.01 0 0 0 0 0</pose><geometry><mesh><uri>tet.obj</uri><scale>0.1 0.1 0.1</scale></mesh></geometry></collision>
+      </link></model></sdf>''')
+    m = sdf2model(ModelSDF.read(str(tmp_path / 'm.sdf'))[0], plane=True, use_collisions=True)
+    assert sorted(m.geom_type.tolist()) == [0, 2, 7] and m.nmeshvert == 4
