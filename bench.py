@@ -229,7 +229,17 @@ def main():
         if args.dist_backend == 'nccl':
             dist.init_process_group('nccl', device_id=torch.device('cuda', local_rank))
         else:
-            dist.init_process_group(args.dist_backend)
+            # gloo announces its connections on the C stdout ("[Gloo] Rank 0 is connected to ..."): keep stdout for the one JSON line
+            sys.stdout.flush()
+            saved = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                dist.init_process_group(args.dist_backend)
+                dist.barrier()
+            finally:
+                sys.stdout.flush()
+                os.dup2(saved, 1)
+                os.close(saved)
     assert world == args.gpus, f'--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU with torch.distributed.run'
     device = f'cuda:{local_rank}'
     torch.cuda.set_device(local_rank)

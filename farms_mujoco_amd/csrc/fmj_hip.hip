@@ -313,6 +313,9 @@ __device__ __forceinline__ float bcast(float v, int lane) {   // lane must be wa
 // (L1/L2-resident) tables inside every step instead of pinning ~40 VGPRs across the whole loop.
 __device__ __forceinline__ int opaque(int x) { asm volatile("" : "+v"(x)); return x; }
 __device__ __forceinline__ float pinf(float x) { asm volatile("" : "+v"(x)); return x; }
+// the same for a wave-uniform value: conditions made from it (f < nefc for 60 columns, lvl < maxdep for 20 levels) are otherwise
+// computed once, kept as SGPR-pair masks for every later use and spilled
+__device__ __forceinline__ int opaque_s(int x) { asm volatile("" : "+s"(x)); return x; }
 // LDS ordering between lanes of the one wave that forms the workgroup
 // (every kernel here runs 64-thread workgroups = one wave: LDS operations of one wave execute in order, so ordering
 // between lanes needs no s_barrier and no s_waitcnt, only that the compiler keeps the program order)
@@ -681,6 +684,7 @@ __device__ __forceinline__ void ldl_factor2(float* HM, float* HR, float* DVM, fl
 template <int MAXD>
 __device__ __forceinline__ float ldl_pull_sweep(const float* HR, float x, int dli, bool isd, int ddepth, const uint32_t* ancl, int maxdep) {
   constexpr int RS = MAXD;
+  maxdep = opaque_s(maxdep);
   float4 row[MAXD / 4];
 #pragma unroll
   for (int g = 0; g < MAXD / 4; g++) row[g] = *(const float4*)(HR + dli * RS + 4 * g);
@@ -939,9 +943,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int dl = isd ? lane : 0;
   // dof-role constants that index loops stay resident (2 VGPRs); everything else is re-read per step
   const int4 d_info0 = DTABI(dl, 0);
-  const int ddepth = isd ? d_info0.y : 0;
-  const int dsub = isd ? d_info0.z : 0;
-  const int dparent = (CONS && isd) ? DTABI(dl, 2).w : 0;
+  const int ddepth_o = isd ? d_info0.y : 0;
+  const int dsub_o = isd ? d_info0.z : 0;
+  const int dparent_o = (CONS && isd) ? DTABI(dl, 2).w : 0;
 
   // ---- load tables + state -------------------------------------------------------------------------
   int warn = 0;
@@ -1023,6 +1027,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const int it = A.iteration0 + step;
     const bool last = step == A.n_steps - 1;
     const int blo = opaque(bl), dlo = opaque(dl);
+    // the lane's depth / subtree size / parent are laundered too: every per-lane predicate made from them (lvl < ddepth for 20
+    // levels, the ancestor tests of the sweeps) is loop-invariant and was hoisted into SGPR pairs - ~100 of them, all spilled
+    const int ddepth = opaque(ddepth_o), dsub = opaque(dsub_o), dparent = opaque(dparent_o);
     // ============ before_step (reference task.py:168-186) ============
     STAMP(0);   // emit links + drag
     if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list

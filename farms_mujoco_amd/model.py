@@ -733,7 +733,7 @@ def salamander33(contacts: bool = False, limits: bool = False, full_actuators: b
             b.add_hfield(0.5*np.sin(7.0*gx)*np.cos(5.0*gy), (2.0, 2.0, 0.01, 0.1), friction=(0, 0, 0))
         else:
             b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))     # arena friction 0 (mjcf.py:1202)
-        b.options['max_contacts'] = 32
+        b.options['max_contacts'] = 40 if mesh_feet else 32     # a mesh foot makes up to 4 contacts (27 limits + 4 x 40 rows <= 192)
         if self_collisions:                 # feet against the trunk segments they can reach and against each other
             assert not mesh_feet, 'explicit pairs need sphere / capsule geoms'
             for tag, trunk in (('front', (0, 2, 3)), ('hind', (4, 6, 7))):

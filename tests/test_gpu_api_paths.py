@@ -340,6 +340,29 @@ def test_blowup_mid_launch_freezes_at_last_finite_state(oracle):
     assert int(good.data.status.abs().sum()) == 0 and abs(float(good.data.time[0]) - T*m.timestep) < 1e-4
 
 
+@pytest.mark.parametrize('maker', ['salamander33', 'centipede'])      # two-env kernel / one-env kernel
+def test_root_position_past_the_limit_mid_launch_is_not_committed(maker):
+    """A root position about to leave the finite range (|x| > 1e10, mj_checkPos) in the middle of a launch is never stored: the
+    env freezes at its last good state (include/fmj.h freeze contract) - with BADQPOS, or with BADQACC / BADQVEL if the fp32
+    dynamics at |x| ~ 1e10 (one ulp = 1 km) gives up first - and the other envs go on."""
+    import torch
+    import farms_mujoco_amd.model as mm
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = getattr(mm, maker)()
+    n, T = 4, 20
+    qpos, qvel, _ = mm.synthetic_batch(m, n)
+    qpos[1, 0] = 1e10 - 4e7; qvel[1, 0] = 9e9           # env 1 crosses 1e10 at its fifth step of 1e-3 s (9e6 m per step)
+    phys = BatchedPhysics(m, n)
+    d = phys.data
+    d.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    phys.step(T)
+    torch.cuda.synchronize()
+    st = d.status.cpu().numpy()
+    assert st[1] & 7 and not st[[0, 2, 3]].any()
+    assert float(d.qpos[1, 0].abs()) <= 1e10 and torch.isfinite(d.qpos).all()
+    assert float(d.time[1]) < T*m.timestep - 1e-6 and abs(float(d.time[0]) - T*m.timestep) < 1e-5
+
+
 # ---- ADVICE: links / xfrc subsets ----------------------------------------------------------------------------------------
 
 def test_links_and_xfrc_subset_rows(oracle):
