@@ -434,7 +434,7 @@ struct LdsLayout {
   int HM, YJ, EP, CT, XS, WW, QW, DI, SD, PO, AT, LC, CH, na;      // constraint path only
   int YF, CF, nfl;                                                  // explicit pairs: fork parts of their rows, fork chain per row
 };
-#define FMJ_NFL 32     // fork rows (8 pair contacts) kept on chip
+#define FMJ_NFL 16     // fork rows (4 pair contacts) kept on chip: with 32 the walker with pairs took 21.3 KB of LDS, 7 workgroups per CU instead of 8
 #define AG_LD 192      // row length of the global PGS matrix (three 64-lane slots)
 #define FMJ_NA 60      // constraint rows handled with one row per lane and A in registers
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
@@ -945,7 +945,6 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
   const int4 d_info0 = DTABI(dl, 0);
   const int ddepth_o = isd ? d_info0.y : 0;
   const int dsub_o = isd ? d_info0.z : 0;
-  const int dparent_o = (CONS && isd) ? DTABI(dl, 2).w : 0;
 
   // ---- load tables + state -------------------------------------------------------------------------
   int warn = 0;
@@ -1027,9 +1026,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     const int it = A.iteration0 + step;
     const bool last = step == A.n_steps - 1;
     const int blo = opaque(bl), dlo = opaque(dl);
-    // the lane's depth / subtree size / parent are laundered too: every per-lane predicate made from them (lvl < ddepth for 20
+    // the lane's depth / subtree size are laundered too: every per-lane predicate made from them (lvl < ddepth for 20
     // levels, the ancestor tests of the sweeps) is loop-invariant and was hoisted into SGPR pairs - ~100 of them, all spilled
-    const int ddepth = opaque(ddepth_o), dsub = opaque(dsub_o), dparent = opaque(dparent_o);
+    const int ddepth = opaque(ddepth_o), dsub = opaque(dsub_o);
     // ============ before_step (reference task.py:168-186) ============
     STAMP(0);   // emit links + drag
     if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list

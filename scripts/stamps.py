@@ -10,6 +10,7 @@ names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L'
 workload = os.environ.get('FMJ_WORKLOAD', 'swim')
 for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
     sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
+    print('lds bytes per env', sim.physics.kernel_info())
     for _ in range(int(os.environ.get('FMJ_STAMP_WARM', '100')) // 100 + 1):
         sim.step_fused(100)
     torch.cuda.synchronize()
@@ -17,6 +18,6 @@ for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
     tot = st.sum()
     print(f'n_envs={n}: cycles/step {tot:.0f}')
     print('  ' + '  '.join(f'{k}:{v:.0f}({100*v/tot:.0f}%)' for k, v in zip(names, st)))
-    if workload == 'walk':
+    if workload.startswith('walk'):
         nc = sim.physics.data.ncon.float()
         print(f'  ncon mean {nc.mean().item():.1f} max {nc.max().item():.0f} env0 {nc[0].item():.0f}')
