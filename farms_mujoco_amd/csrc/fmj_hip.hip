@@ -88,6 +88,8 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
+  int solver, ls_iterations;  // FMJ_SOLVER_PGS / FMJ_SOLVER_NEWTON (the NEWTON instantiation of the constraint kernel); Newton line search
+  float ls_tolerance;
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
   int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
@@ -908,7 +910,9 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 // PAIRS: the model has explicit geom pairs (rows over two branches of the tree) or mesh geoms; a separate instantiation
 // because the fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills (and the mesh
 // vertex loop another 20).
-template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false>
+// NEWTON: the constraint forces come from MuJoCo's Newton solver on the primal problem instead of PGS on the dual one (see the
+// Newton block of fmj_cons_rows.inc); models without explicit pairs / mesh geoms.
+template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
   // the two arguments are read where they are used, through the kernarg segment (scalar loads), instead of being held
@@ -1393,6 +1397,11 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       // (1) factor M and H (together, see ldl_factor2), qacc_smooth = M^-1 qfrc_smooth
       float dinv_m;
       float xs = isd ? qfrc : 0.f;
+      f2_t mrow[MAXD / 2];              // NEWTON: the rows of M itself stay in registers (the Hessian M + J'DJ is rebuilt from them)
+      if (NEWTON) {
+#pragma unroll
+        for (int d = 0; d < MAXD / 2; d++) mrow[d] = hrow[d];
+      }
       ldl_factor2<MAXD>(HM, HR, DI, XV, M.rounds1, M.nround1, lane, isd, ddepth, hrow, hdg_m, hdg_h, dinv_m, dinv_h, xs);
       xs = ldl_pull_sweep<MAXD>(HM, xs * dinv_m, isd ? lane : 0, isd, ddepth, M.ancl1, M.maxdep1);
       if (isd) { XS[lane] = xs; DI[lane] = dinv_m; SD[lane] = sqrtf(dinv_m); XV[lane] = dinv_h; }   // 1 / D of H waits in XV
@@ -1735,6 +1744,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 3) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true>;
   if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
@@ -1871,7 +1881,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs / meshes, 3 Newton solver
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1885,7 +1895,10 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   }
   return (step_kernel_t)k;
 }
-static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) { return tu_kernel(c->dm.rs, fused, c->dm.cons ? ((c->dm.npair > 0 || c->dm.any_mesh) ? 2 : 1) : 0, 0); }
+static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? 3 : ((c->dm.npair > 0 || c->dm.any_mesh) ? 2 : 1));
+  return tu_kernel(c->dm.rs, fused, cons, 0);
+}
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
     step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 3 ? 3 : 2);
@@ -1976,7 +1989,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (m->geom_bodyid[g1] == m->geom_bodyid[g2]) return set_err(FMJ_ERR_ARG, "fmj_create: a contact pair joins geoms of two bodies");
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
-  if (cons && m->solver != FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements solver = PGS (FMJ_SOLVER_PGS) only");
+  if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements solver = PGS or Newton (FMJ_SOLVER_PGS / FMJ_SOLVER_NEWTON), not CG");
+  if (cons && m->solver == FMJ_SOLVER_NEWTON && (m->npair > 0 || any_mesh)) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton solver of the HIP path covers limits and ground contacts of sphere / capsule / box / cylinder geoms (its Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs, no mesh geoms");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements the pyramidal friction cone only");
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
@@ -2158,6 +2172,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
   }
   D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
+  D.solver = cons ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
+  D.ls_tolerance = (float)(m->ls_tolerance > 0 ? m->ls_tolerance : 0.01);
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
   D.pgs_scale = (float)(1.0 / ((m->meaninertia > 0 ? m->meaninertia : 1.0) * (nv > 1 ? nv : 1)));
   std::vector<int> d_parent(64, -1);
