@@ -438,7 +438,7 @@ struct LdsLayout {
 };
 #define FMJ_NFL 16     // fork rows (4 pair contacts) kept on chip: with 32 the walker with pairs took 21.3 KB of LDS, 7 workgroups per CU instead of 8
 #define AG_LD 192      // row length of the global PGS matrix (three 64-lane slots)
-#define FMJ_NA 60      // constraint rows handled with one row per lane and A in registers
+#define FMJ_NA 64      // constraint rows handled with one row per lane and A in registers (every lane a row)
 __host__ __device__ inline LdsLayout lds_layout(int nb, int nv, int nq, int rs, int anc_stride, int cons = 0, int maxefc = 0,
                                                 int maxcon = 0, int nvs = 0, int npair = 0) {
   LdsLayout L;
@@ -912,7 +912,9 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 // vertex loop another 20).
 // NEWTON: the constraint forces come from MuJoCo's Newton solver on the primal problem instead of PGS on the dual one (see the
 // Newton block of fmj_cons_rows.inc); models without explicit pairs / mesh geoms.
-template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false>
+// MESH: the narrow phase has the convex-mesh vertex loop (~20 VGPRs); on by itself for models with mesh geoms but no explicit pairs,
+// which then do not pay for the fork code of PAIRS (its spills cost the mesh-foot walker 52 KB of scratch traffic per env-step).
+template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false, bool MESH = PAIRS>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
   // the two arguments are read where they are used, through the kernarg segment (scalar loads), instead of being held
@@ -1513,7 +1515,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               for (int k = 0; k < 4; k++) nq[k] = nrm_;
             }
           }
-          if (PAIRS && M.any_mesh) {      // convex mesh: its deepest penetrating vertices, deepest first (include/fmj.h)
+          if (MESH && M.any_mesh) {      // convex mesh: its deepest penetrating vertices, deepest first (include/fmj.h)
             const int4 gi = g < M.ngeom ? GTABI(g, 0) : make_int4(-1, 0, 0, 0);
             if (gi.x == FMJ_GEOM_MESH) {
               const float4 gs = GTAB(g, 1), gp = GTAB(g, 2), gq = GTAB(g, 3);
@@ -1642,7 +1644,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
       const int e_p0 = nlim + 4 * ncg;              // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
       const bool hasp = PAIRS && M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
-      if (nefc <= LL.na && nefc - e_p0 <= LL.nfl) {
+      // an env with an active pair contact (rare) takes the HBM path: the register path then carries no fork code at all
+      if (nefc <= LL.na && !hasp) {
         constexpr bool small = true;
         float* const YC = YJ;
         float* const EP = EPL;
@@ -1744,6 +1747,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 4) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true>;
   if (cons == 3) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true>;
   if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
@@ -1881,7 +1885,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs / meshes, 3 Newton solver
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton solver, 4 + meshes only
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1896,7 +1900,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? 3 : ((c->dm.npair > 0 || c->dm.any_mesh) ? 2 : 1));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? 3 : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
