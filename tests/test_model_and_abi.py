@@ -118,3 +118,37 @@ def test_create_without_gpu_fails_loudly():
         m = salamander33(); c = m.as_c(); ctx = ctypes.c_void_p()
         rc = lib.fmj_create(ctypes.byref(c), 4, 0, ctypes.byref(ctx))
         assert rc == 4 and b'no HIP device' in lib.fmj_last_error()       # FMJ_ERR_NODEVICE
+
+
+def test_model_size_limits_are_refused_with_a_message_that_names_them():
+    """One wavefront per environment: more than 64 bodies / dofs, or a dof chain longer than 32, is FMJ_ERR_UNSUPPORTED with the limit
+    in the message ('Model size'; the reference itself has no such limit, mjcf.py:1327-1328).  fmj_create validates
+    the model before it looks for a device, so this runs without a GPU."""
+    from farms_mujoco_amd import _lib
+    from farms_mujoco_amd.model import eel, SOLVERS
+    if not os.path.exists(_lib.SO_PATH):
+        pytest.skip('libfmj_hip.so not built')
+    lib = _lib.load()
+
+    def create(m):
+        c = m.as_c(); ctx = ctypes.c_void_p()
+        rc = lib.fmj_create(ctypes.byref(c), 4, 0, ctypes.byref(ctx))
+        if rc == 0:
+            lib.fmj_destroy(ctx)
+        return rc, lib.fmj_last_error().decode()
+    rc, msg = create(eel(n_joints=70))                       # 71 bodies, nv 76
+    assert rc == 2 and '64' in msg and 'wavefront' in msg, (rc, msg)
+    rc, msg = create(eel(n_joints=40))                       # nv 46 fits a wave, its dof chain of 46 does not fit the register row
+    assert rc == 2 and 'chain longer than 32' in msg, (rc, msg)
+    m = salamander33(contacts=True, limits=True)
+    m.solver = SOLVERS['cg']
+    rc, msg = create(m)
+    assert rc == 2 and 'PGS or Newton' in msg, (rc, msg)
+    m = salamander33(contacts=True, limits=True, self_collisions=True)
+    m.solver = SOLVERS['newton']
+    rc, msg = create(m)
+    assert rc == 2 and 'no explicit pairs' in msg, (rc, msg)
+    m = salamander33(contacts=True, limits=True)
+    m.cone = 1
+    rc, msg = create(m)
+    assert rc == 2 and 'pyramidal' in msg, (rc, msg)
