@@ -6,7 +6,7 @@ from farms_mujoco_amd import _lib
 _lib.SO_PATH = os.path.join(_lib.CSRC, 'libfmj_hip_stamps.so')
 import torch, bench
 names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L', 'X', 'Euler', 'facM', 'collide', 'Jrows', 'rowprm', 'Y',
-         'A', 'warm', 'PGS', 'qfrc_c', '-', '-', '-']
+         'A|nwt-start', 'warm|nwt-H', 'PGS|nwt-update', 'qfrc_c', 'nwt-factor', 'nwt-solve', 'nwt-linesearch']
 workload = os.environ.get('FMJ_WORKLOAD', 'swim')
 for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
     sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
