@@ -1746,6 +1746,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #define FMJ_CAT(a, b) FMJ_CAT2(a, b)
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
+  if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
   if (cons == 4) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true>;
   if (cons == 3) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true>;
@@ -1905,7 +1906,7 @@ static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 3 ? 3 : 2);
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 2 ? 4 : (c->dual_wps == 3 ? 3 : 2));
     hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual2, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
@@ -2399,9 +2400,10 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     int n_cu = 256;
     if (hipGetDeviceProperties(&prop, device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount;
     const int waves = (n_envs + 1) / 2;
-    c->dual_wps = waves <= 3 * 4 * n_cu ? 3 : 4;          // at most three waves per SIMD anyway: take the 168-register build (nothing spilled)
+    // the build registered for the waves per SIMD the batch can fill: 2 (256 registers: model constants resident), 3 (168) or 4 (128)
+    c->dual_wps = waves <= 2 * 4 * n_cu ? 2 : (waves <= 3 * 4 * n_cu ? 3 : 4);
     const char* w = getenv("FMJ_WPS");
-    if (w && (w[0] == '3' || w[0] == '4')) c->dual_wps = w[0] - '0';
+    if (w && (w[0] == '2' || w[0] == '3' || w[0] == '4')) c->dual_wps = w[0] - '0';
   }
   if (c->lds_bytes > 64 * 1024) {
     hipError_t e1 = hipFuncSetAttribute((const void*)pick_kernel(c, true), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c->lds_bytes);
