@@ -911,7 +911,7 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 // because the fork handling costs ~150 VGPRs that every constraint model would otherwise pay for in spills (and the mesh
 // vertex loop another 20).
 // NEWTON: the constraint forces come from MuJoCo's Newton solver on the primal problem instead of PGS on the dual one (see the
-// Newton block of fmj_cons_rows.inc); models without explicit pairs / mesh geoms.
+// Newton block of fmj_cons_rows.inc); models without explicit pairs.
 // MESH: the narrow phase has the convex-mesh vertex loop (~20 VGPRs); on by itself for models with mesh geoms but no explicit pairs,
 // which then do not pay for the fork code of PAIRS (its spills cost the mesh-foot walker 52 KB of scratch traffic per env-step).
 template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false, bool MESH = PAIRS>
@@ -1748,6 +1748,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 5) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true>;
   if (cons == 4) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true>;
   if (cons == 3) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true>;
   if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
@@ -1886,7 +1887,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton solver, 4 + meshes only
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton solver, 4 + meshes only, 5 Newton + meshes
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1901,7 +1902,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? 3 : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? (c->dm.any_mesh ? 5 : 3) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
@@ -1995,7 +1996,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
   if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements solver = PGS or Newton (FMJ_SOLVER_PGS / FMJ_SOLVER_NEWTON), not CG");
-  if (cons && m->solver == FMJ_SOLVER_NEWTON && (m->npair > 0 || any_mesh)) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton solver of the HIP path covers limits and ground contacts of sphere / capsule / box / cylinder geoms (its Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs, no mesh geoms");
+  if (cons && m->solver == FMJ_SOLVER_NEWTON && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton solver of the HIP path covers limits and ground contacts (its Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements the pyramidal friction cone only");
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");

@@ -93,11 +93,36 @@ def test_newton_walk_follows_the_oracle(oracle):
     assert np.median(e) < 1e-4 and e.max() < 1e-3 and np.median(e) < 40*np.median(f)
 
 
-def test_newton_refused_for_pairs_and_meshes():
+def test_newton_with_mesh_feet_on_a_heightfield(oracle):
+    """The reference's usual configuration - SDF mesh collisions (mjcf.py:270-413) under its fallback solver Newton (:1348-1359) - here
+    on a heightfield: 60 steps of standing / settling against the oracle's Newton."""
+    import torch
+    from farms_mujoco_amd.model import salamander33, SOLVERS
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = salamander33(contacts=True, limits=True, spawn_z=0.05, mesh_feet=True, terrain='hfield')
+    m.solver = SOLVERS['newton']; m.solver_iterations = 100
+    n, T = 6, 60
+    rng = np.random.default_rng(3)
+    qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.1, 0.1, (n, m.nq - 7)); qpos[:, :2] += rng.uniform(-0.3, 0.3, (n, 2))
+    phys = BatchedPhysics(m, n)
+    q32, v32, _ = _set(phys, qpos, np.zeros((n, m.nv)))
+    phys.step(T)
+    torch.cuda.synchronize()
+    ref = oracle.step(m, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=T)
+    d = phys.data
+    assert int(d.status.abs().sum()) == 0 and int(ref['status'].sum()) == 0
+    fds = [oracle.forward_debug(m, ref['qpos'][e], ref['qvel'][e], ctrl=np.zeros(m.nu)) for e in range(n)]
+    assert max(fd['ncon'] for fd in fds) >= 4
+    e = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print('Newton, mesh feet on a heightfield, qpos abs err per env after', T, 'steps:', e)
+    assert e.max() < 1e-3
+
+
+def test_newton_refused_for_pairs_and_cg():
     from farms_mujoco_amd.model import salamander33, SOLVERS
     from farms_mujoco_amd.physics import BatchedPhysics
     from farms_mujoco_amd._lib import FmjError
-    for kw in (dict(self_collisions=True), dict(mesh_feet=True)):
+    for kw in (dict(self_collisions=True),):
         m = salamander33(contacts=True, limits=True, spawn_z=0.045, **kw)
         m.solver = SOLVERS['newton']
         with pytest.raises(FmjError):
