@@ -88,7 +88,7 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
-  int solver, ls_iterations;  // FMJ_SOLVER_PGS / FMJ_SOLVER_NEWTON (the NEWTON instantiation of the constraint kernel); Newton line search
+  int solver, ls_iterations;  // FMJ_SOLVER_PGS, or FMJ_SOLVER_NEWTON / FMJ_SOLVER_CG (both the NEWTON instantiation of the constraint kernel); line search
   float ls_tolerance;
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
   int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
@@ -1902,7 +1902,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver == FMJ_SOLVER_NEWTON ? (c->dm.any_mesh ? 5 : 3) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.any_mesh ? 5 : 3) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
@@ -1995,8 +1995,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (m->geom_bodyid[g1] == m->geom_bodyid[g2]) return set_err(FMJ_ERR_ARG, "fmj_create: a contact pair joins geoms of two bodies");
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
-  if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements solver = PGS or Newton (FMJ_SOLVER_PGS / FMJ_SOLVER_NEWTON), not CG");
-  if (cons && m->solver == FMJ_SOLVER_NEWTON && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton solver of the HIP path covers limits and ground contacts (its Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs");
+  if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON && m->solver != FMJ_SOLVER_CG) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: solver must be FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON");
+  if (cons && m->solver != FMJ_SOLVER_PGS && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton / CG solvers of the HIP path cover limits and ground contacts (the Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements the pyramidal friction cone only");
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");

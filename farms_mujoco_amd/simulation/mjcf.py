@@ -50,7 +50,7 @@ def check_supported_options(simulation_options):
     silently run different physics: refuse it."""
     if simulation_options is None:
         return
-    for name, supported in (('integrator', ('euler',)), ('cone', ('pyramidal',)), ('solver', ('pgs', 'newton'))):
+    for name, supported in (('integrator', ('euler',)), ('cone', ('pyramidal',)), ('solver', ('pgs', 'cg', 'newton'))):
         value = getattr(simulation_options, name, None)
         if value is not None and str(value).lower() not in supported:
             raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {" / ".join(supported)} only '

@@ -184,9 +184,8 @@ typedef struct fmj_model {
   double solver_tolerance;
   double meaninertia;           /* mjModel.stat.meaninertia: mean diagonal of M at qpos0 (solver termination scale) */
   /* ABI 4 */
-  int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353).  HIP path: PGS (any model of the subset) or Newton
-                                   (limits + ground contacts, mesh geoms included: no explicit pairs);
-                                   the oracle also has CG */
+  int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353).  HIP path: PGS (any model of the subset), Newton or CG
+                                   (limits + ground contacts, mesh geoms included: no explicit pairs) */
   int32_t cone;                 /* FMJ_CONE_*:   option.cone   (mjcf.py:1342-1347) */
   int32_t ls_iterations;        /* Newton / CG line-search iterations (MuJoCo option.ls_iterations, default 50); <= 0: 50 */
   int32_t noslip_iterations;    /* option.noslip_iterations (mjcf.py:1392-1397); 0 = off */

@@ -11,10 +11,10 @@ from parity_metrics import group_relerr, qvel_groups
 pytestmark = pytest.mark.gpu
 
 
-def _walker(spawn_z=0.045):
+def _walker(spawn_z=0.045, solver='newton'):
     from farms_mujoco_amd.model import salamander33, SOLVERS
     m = salamander33(contacts=True, limits=True, spawn_z=spawn_z)
-    m.solver = SOLVERS['newton']; m.solver_iterations = 100
+    m.solver = SOLVERS[solver]; m.solver_iterations = 100
     return m
 
 
@@ -28,12 +28,13 @@ def _set(phys, qpos, qvel, warm=None):
     return r64(d.qpos), r64(d.qvel), r64(d.qacc_warmstart)
 
 
-def test_newton_single_step_forces_and_kkt(oracle):
+@pytest.mark.parametrize('solver', ['newton', 'cg'])
+def test_newton_single_step_forces_and_kkt(oracle, solver):
     """Feet on the floor, bellies pressed in (more than 64 rows), a joint past its limit: contact list, forces and velocity of one
     step against the oracle's Newton; the forces satisfy the KKT conditions of the fp64 problem."""
     import torch
     from farms_mujoco_amd.physics import BatchedPhysics
-    m = _walker()
+    m = _walker(solver=solver)
     n = 12
     rng = np.random.default_rng(0)
     qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.1, 0.1, (n, m.nq - 7))
@@ -60,19 +61,20 @@ def test_newton_single_step_forces_and_kkt(oracle):
         r = AR @ f_h + b
         assert f_h.min() >= 0.0 and r.min() > -2e-3*bs and np.abs(f_h*r).max() < 2e-3*fs*bs, (e, r.min()/bs, np.abs(f_h*r).max()/(fs*bs))
     err = group_relerr(d.qvel.cpu().numpy(), o['qvel'], qvel_groups(m)); floor = group_relerr(fl['qvel'], o['qvel'], qvel_groups(m))
-    print('Newton single step: forces', worst, 'qvel per component', err, 'fp32-storage floor', floor)
+    print(solver, 'single step: forces', worst, 'qvel per component', err, 'fp32-storage floor', floor)
     assert worst < 2e-3
     assert err < 6*floor + 1e-6
     assert np.abs(d.qacc_warmstart.cpu().numpy() - o['warmstart']).max() < 2e-3*np.abs(o['warmstart']).max()
 
 
-def test_newton_walk_follows_the_oracle(oracle):
+@pytest.mark.parametrize('solver', ['newton', 'cg'])
+def test_newton_walk_follows_the_oracle(oracle, solver):
     """300 steps of the trot with the Newton solver, fused loop with contact rows: no warning bits, the floor carries the animal,
     and since Newton converges at every step (unlike PGS cut at 50 sweeps) the walk stays on the oracle's."""
     import torch
     from farms_mujoco_amd.physics import BatchedPhysics
     from test_gpu_contacts import _trot_tape
-    m = _walker()
+    m = _walker(solver=solver)
     n, T = 8, 300
     tape = _trot_tape(m, n, T)
     phys = BatchedPhysics(m, n)
@@ -86,7 +88,7 @@ def test_newton_walk_follows_the_oracle(oracle):
     d = phys.data
     assert int(d.status.abs().sum()) == 0 and int(ref['status'].sum()) == 0
     e = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1); f = np.abs(fl['qpos'] - ref['qpos']).max(1)
-    print('Newton walk, qpos abs err per env after', T, 'steps:', e, 'fp32-storage floor run:', f)
+    print(solver, 'walk, qpos abs err per env after', T, 'steps:', e, 'fp32-storage floor run:', f)
     assert float(d.qpos[:, 2].min()) > 0.0 and float(d.qpos[:, 2].max()) < 0.1
     # 10 - 20x the fp32-storage floor of the same 300 steps (the order in which the Hessian rows are summed moves it between builds),
     # an order of magnitude inside the bounds of the PGS walk (5e-4 median, 5e-3 worst)
@@ -118,16 +120,12 @@ def test_newton_with_mesh_feet_on_a_heightfield(oracle):
     assert e.max() < 1e-3
 
 
-def test_newton_refused_for_pairs_and_cg():
+def test_newton_and_cg_refused_for_pairs():
     from farms_mujoco_amd.model import salamander33, SOLVERS
     from farms_mujoco_amd.physics import BatchedPhysics
     from farms_mujoco_amd._lib import FmjError
-    for kw in (dict(self_collisions=True),):
-        m = salamander33(contacts=True, limits=True, spawn_z=0.045, **kw)
-        m.solver = SOLVERS['newton']
+    for solver in ('newton', 'cg'):
+        m = salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=True)
+        m.solver = SOLVERS[solver]
         with pytest.raises(FmjError):
             BatchedPhysics(m, 2)
-    m = salamander33(contacts=True, limits=True, spawn_z=0.045)
-    m.solver = SOLVERS['cg']
-    with pytest.raises(FmjError):
-        BatchedPhysics(m, 2)

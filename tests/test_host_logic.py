@@ -166,14 +166,15 @@ def test_iterator_physics_error_policy():
 
 
 def test_unsupported_solver_options_are_refused():
-    """integrator / cone / solver other than Euler / pyramidal / PGS or Newton must not silently run different physics
+    """integrator / cone / solver other than Euler / pyramidal / PGS, CG or Newton must not silently run different physics
     (the reference forwards them to MuJoCo, mjcf.py:1342-1365)."""
     from farms_mujoco_amd.options import SimulationOptions
     from farms_mujoco_amd.simulation.mjcf import check_supported_options
     check_supported_options(SimulationOptions())
-    check_supported_options(SimulationOptions(solver='Newton'))        # round 3: the device has MuJoCo's Newton solver too
+    check_supported_options(SimulationOptions(solver='Newton'))        # round 3: the device has MuJoCo's Newton and CG solvers too
+    check_supported_options(SimulationOptions(solver='CG'))
     check_supported_options(None)
-    for kw in (dict(cone='elliptic'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='CG')):
+    for kw in (dict(cone='elliptic'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='SOR')):
         with pytest.raises(NotImplementedError):
             check_supported_options(SimulationOptions(**kw))
 

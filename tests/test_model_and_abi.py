@@ -141,9 +141,9 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     rc, msg = create(eel(n_joints=40))                       # nv 46 fits a wave, its dof chain of 46 does not fit the register row
     assert rc == 2 and 'chain longer than 32' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True)
-    m.solver = SOLVERS['cg']
+    m.solver = 7
     rc, msg = create(m)
-    assert rc == 2 and 'PGS or Newton' in msg, (rc, msg)
+    assert rc == 2 and 'FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True, self_collisions=True)
     m.solver = SOLVERS['newton']
     rc, msg = create(m)
