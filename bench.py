@@ -59,8 +59,10 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
     if workload.startswith('walk'):       # walk_pairs / walk_hfield / walk_mesh: the same walker with self-collision pairs, on a heightfield, on mesh feet
         m = mm.salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=workload == 'walk_pairs',
                             terrain='hfield' if workload == 'walk_hfield' else 'plane', mesh_feet=workload == 'walk_mesh')
-        if workload in ('walk_newton', 'walk_cg'):     # MuJoCo's Newton / CG solver with its default settings instead of PGS x 50
-            m.solver = mm.SOLVERS[workload[5:]]; m.solver_iterations = 100
+        if workload in ('walk_newton', 'walk_cg', 'walk_elliptic'):     # MuJoCo's Newton / CG solver with its default settings instead of PGS x 50
+            m.solver = mm.SOLVERS['cg' if workload == 'walk_cg' else 'newton']; m.solver_iterations = 100
+            if workload == 'walk_elliptic':
+                m.cone = mm.CONES['elliptic']
     else:
         m = getattr(mm, morphology)()
     qpos, qvel, psi = mm.synthetic_batch(m, n_envs, seed=0, env_offset=env_offset)
@@ -206,7 +208,7 @@ def main():
                     help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the short walk / mixed measurements appended to the swim line')
-    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh', 'walk_newton', 'walk_cg'],
+    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh', 'walk_newton', 'walk_cg', 'walk_elliptic'],
                     help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede; walk_pairs / '
                          'walk_hfield / walk_mesh = the walker with self-collision pairs / on a heightfield / on convex-mesh feet')
     ap.add_argument('--dist-backend', default='gloo',
@@ -327,7 +329,7 @@ def main():
             pass
         names = {'swim': 'salamander swim (~40 DoF)', 'walk': 'salamander walk on plane (PGS contacts)', 'mixed': 'eel + centipede swim (bucketed)',
                  'walk_pairs': 'salamander walk on plane with self-collision pairs', 'walk_hfield': 'salamander walk on a heightfield',
-                 'walk_mesh': 'salamander walk on convex-mesh feet', 'walk_newton': 'salamander walk on plane (Newton solver)', 'walk_cg': 'salamander walk on plane (CG solver)'}
+                 'walk_mesh': 'salamander walk on convex-mesh feet', 'walk_newton': 'salamander walk on plane (Newton solver)', 'walk_cg': 'salamander walk on plane (CG solver)', 'walk_elliptic': 'salamander walk on plane (Newton solver, elliptic cone)'}
         out = {
             'metric': f'env-steps/sec, {names[args.workload]} \u00d7{n_envs} envs, 1/2/4/8 MI355X',
             'value': n_envs*world*K*R/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -345,6 +347,7 @@ def main():
                                     'walk_mesh': f'{n_envs}x salamander-33 walking on a plane on convex-mesh feet (12-vertex hulls)',
                                     'walk_newton': f'{n_envs}x salamander-33 walking on a plane, Newton solver (tolerance 1e-8, <= 100 iterations) instead of PGS',
                                     'walk_cg': f'{n_envs}x salamander-33 walking on a plane, CG solver (tolerance 1e-8, <= 100 iterations) instead of PGS',
+                                    'walk_elliptic': f'{n_envs}x salamander-33 walking on a plane, Newton solver with the elliptic friction cone',
                                     'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
                                              f'GPU, one bucket (launch, HIP stream) per morphology, launched side by side'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',

@@ -88,6 +88,7 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
+  int cone;                   // FMJ_CONE_PYRAMIDAL, or FMJ_CONE_ELLIPTIC (Newton / CG only: three rows per contact, cone cost in fmj_newton.inc)
   int solver, ls_iterations;  // FMJ_SOLVER_PGS, or FMJ_SOLVER_NEWTON / FMJ_SOLVER_CG (both the NEWTON instantiation of the constraint kernel); line search
   float ls_tolerance;
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
@@ -914,7 +915,7 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 // Newton block of fmj_cons_rows.inc); models without explicit pairs.
 // MESH: the narrow phase has the convex-mesh vertex loop (~20 VGPRs); on by itself for models with mesh geoms but no explicit pairs,
 // which then do not pay for the fork code of PAIRS (its spills cost the mesh-foot walker 52 KB of scratch traffic per env-step).
-template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false, bool MESH = PAIRS>
+template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false, bool MESH = PAIRS, bool ELL = false>
 __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
   // the two arguments are read where they are used, through the kernarg segment (scalar loads), instead of being held
@@ -1634,7 +1635,9 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       }
       if (ncon > M.max_contacts) { ncon = M.max_contacts; warn |= FMJ_WARN_CONTACTFULL; }
       if (ncg > ncon) ncg = ncon;
-      const int nefc = nlim + 4 * ncon;
+      // rows per contact: the four edges of the friction pyramid, or - elliptic cone, Newton / CG only - the three axes of the contact frame
+      constexpr int crs = ELL ? 3 : 4;          // ELL: its own instantiation (with NEWTON and MESH), so that the pyramidal kernels carry none of it
+      const int nefc = nlim + crs * ncon;
       WSYNC();
       STAMP(13);  // limits + contacts
       // (4) Jacobian rows, stored compactly: a row touches only the dofs on the chain from its body to the root, so
@@ -1642,7 +1645,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
       //     dof (+1).  Limit rows: +-1 at the dof.  Contact rows: n.Jp +- mu t.Jp, Jp column of dof d = cdof_lin + cdof_rot x (p - com).
       //     Up to LL.na rows everything stays on chip ("small": the rows overlay T/F, V/BUF and CI, dead by now); with
       //     more rows the row vectors, the per-row parameters and A live in a per-env HBM scratch.
-      const int e_p0 = nlim + 4 * ncg;              // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
+      const int e_p0 = nlim + crs * ncg;            // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
       const bool hasp = PAIRS && M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
       // an env with an active pair contact (rare) takes the HBM path: the register path then carries no fork code at all
       if (nefc <= LL.na && !hasp) {
@@ -1748,6 +1751,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 6) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true, true>;
   if (cons == 5) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true>;
   if (cons == 4) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true>;
   if (cons == 3) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true>;
@@ -1887,7 +1891,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton solver, 4 + meshes only, 5 Newton + meshes
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes)
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1902,7 +1906,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.any_mesh ? 5 : 3) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.cone == FMJ_CONE_ELLIPTIC ? 6 : (c->dm.any_mesh ? 5 : 3)) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
@@ -1997,7 +2001,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
   if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON && m->solver != FMJ_SOLVER_CG) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: solver must be FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON");
   if (cons && m->solver != FMJ_SOLVER_PGS && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton / CG solvers of the HIP path cover limits and ground contacts (the Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs");
-  if (cons && m->cone != FMJ_CONE_PYRAMIDAL) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the HIP constraint path implements the pyramidal friction cone only");
+  if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
+  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG (the PGS kernel implements the pyramidal cone only)");
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
@@ -2178,6 +2183,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
   }
   D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
+  D.cone = cons ? m->cone : FMJ_CONE_PYRAMIDAL;
   D.solver = cons ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
   D.ls_tolerance = (float)(m->ls_tolerance > 0 ? m->ls_tolerance : 0.01);
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));

@@ -45,16 +45,18 @@ def get_local_transform(parent_pose, child_pose):
 
 
 def check_supported_options(simulation_options):
-    """The step runs semi-implicit Euler with a pyramidal cone and either PGS or Newton; the reference forwards
+    """The step runs semi-implicit Euler with PGS (pyramidal cone) or Newton / CG (pyramidal or elliptic cone); the reference forwards
     ``simulation_options.integrator / cone / solver`` to MuJoCo's option block (mjcf.py:1342-1365), so any other request would
     silently run different physics: refuse it."""
     if simulation_options is None:
         return
-    for name, supported in (('integrator', ('euler',)), ('cone', ('pyramidal',)), ('solver', ('pgs', 'cg', 'newton'))):
+    for name, supported in (('integrator', ('euler',)), ('cone', ('pyramidal', 'elliptic')), ('solver', ('pgs', 'cg', 'newton'))):
         value = getattr(simulation_options, name, None)
         if value is not None and str(value).lower() not in supported:
             raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {" / ".join(supported)} only '
-                                      '(Euler with implicit joint damping, pyramidal friction cone, PGS or Newton)')
+                                      '(Euler with implicit joint damping; PGS with the pyramidal cone, Newton / CG with either cone)')
+    if str(getattr(simulation_options, 'cone', 'pyramidal')).lower() == 'elliptic' and str(getattr(simulation_options, 'solver', 'PGS')).lower() == 'pgs':
+        raise NotImplementedError("simulation_options.cone='elliptic' needs solver='Newton' or 'CG' on the HIP path (its PGS kernel implements the pyramidal cone)")
 
 
 def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
@@ -89,6 +91,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
         b.options['solver_iterations'] = int(simulation_options.n_solver_iters)
         b.options['impratio'] = float(simulation_options.impratio)
         b.options['solver'] = str(getattr(simulation_options, 'solver', 'PGS'))       # mjcf.py:1348-1353
+        b.options['cone'] = str(getattr(simulation_options, 'cone', 'pyramidal'))     # mjcf.py:1342-1347
 
     link_opts = {l.name: l for l in animat_options.morphology.links} if animat_options is not None else {}
     joint_opts = {j.name: j for j in animat_options.morphology.joints} if animat_options is not None else {}
@@ -304,7 +307,7 @@ def model2mjcf_xml(m: Model) -> str:
     root = ET.Element('mujoco', model=str(getattr(m, 'name', 'animat')))
     ET.SubElement(root, 'compiler', angle='radian', eulerseq='xyz', inertiafromgeom='false', balanceinertia='false',
                   boundmass='0', boundinertia='0', fusestatic='true')
-    ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone='pyramidal',
+    ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone={0: 'pyramidal', 1: 'elliptic'}[int(getattr(m, 'cone', 0))],
                   solver={0: 'PGS', 1: 'CG', 2: 'Newton'}[int(getattr(m, 'solver', 0))], iterations=str(int(m.solver_iterations)), tolerance=repr(float(m.solver_tolerance)),
                   impratio=repr(float(m.impratio)))
     ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))

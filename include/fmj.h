@@ -186,7 +186,8 @@ typedef struct fmj_model {
   /* ABI 4 */
   int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353).  HIP path: PGS (any model of the subset), Newton or CG
                                    (limits + ground contacts, mesh geoms included: no explicit pairs) */
-  int32_t cone;                 /* FMJ_CONE_*:   option.cone   (mjcf.py:1342-1347) */
+  int32_t cone;                 /* FMJ_CONE_*:   option.cone   (mjcf.py:1342-1347).  HIP path: pyramidal with any solver, elliptic with
+                                   Newton / CG (three rows per contact in fmj_step_debug's rows; maxefc stays the 4-per-contact bound) */
   int32_t ls_iterations;        /* Newton / CG line-search iterations (MuJoCo option.ls_iterations, default 50); <= 0: 50 */
   int32_t noslip_iterations;    /* option.noslip_iterations (mjcf.py:1392-1397); 0 = off */
   double ls_tolerance;          /* option.ls_tolerance (default 0.01); <= 0: 0.01 */

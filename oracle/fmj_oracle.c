@@ -136,7 +136,7 @@ typedef struct ws_t {
   int disable_actuation;      /* mj_forward with mjDSBL_ACTUATION (what dm_control runs after physics.reset, task.py:137) */
 } ws_t;
 
-enum { EFC_LIMIT = 0, EFC_CONTACT = 1 };
+enum { EFC_LIMIT = 0, EFC_CONTACT = 1, EFC_ELLIPTIC = 2 };   /* EFC_ELLIPTIC: the rows (normal, tangent 1, tangent 2) of a contact under cone = elliptic */
 
 static double* dalloc(size_t n) { return (double*)calloc(n ? n : 1, sizeof(double)); }
 
@@ -754,6 +754,14 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
     double mu = w->con_mu[c];
     double tran = m->body_invweight0[2 * b] + m->body_invweight0[2 * m->geom_bodyid[w->con_plane[c]]];
     w->con_efc[c] = w->nefc;
+    if (m->cone == FMJ_CONE_ELLIPTIC) {
+      /* mj_instantiateContact, elliptic cone, condim 3: one row per axis of the contact frame; only the normal row has a
+       * position (dist, margin 0), the friction rows have pos = margin = 0 */
+      for (int r = 0; r < 3; r++) {
+        int e = add_efc(m, w, r == 0 ? buf : (r == 1 ? jt1 : jt2), r == 0 ? w->con_dist[c] : 0.0, 0.0, EFC_ELLIPTIC, c);
+        if (e >= 0) w->efc_diagApprox[e] = tran;
+      }
+    } else
     for (int r = 0; r < 4; r++) {
       const double* jt = r < 2 ? jt1 : jt2;
       double sgn = (r & 1) ? -1.0 : 1.0;
@@ -778,6 +786,7 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
       K = 1.0 / fmax(MINVAL, dmax * dmax * tc * tc * dr * dr);
       B = 2.0 / fmax(MINVAL, dmax * tc);
     } else { K = -solref[0] / fmax(MINVAL, dmax * dmax); B = -solref[1] / fmax(MINVAL, dmax); }
+    if (w->efc_type[e] == EFC_ELLIPTIC && e > w->con_efc[w->efc_id[e]]) K = 0;   /* friction rows have no position term (mj_makeImpedance) */
     w->efc_R[e] = fmax(MINVAL, (1 - imp) * w->efc_diagApprox[e] / imp);
     double vel = dotn(w->efc_J + (size_t)e * nv, qvel, nv);
     w->efc_aref[e] = -B * vel - K * imp * (w->efc_pos[e] - w->efc_margin[e]);
@@ -785,11 +794,143 @@ static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, co
   /* pyramidal: all rows of a contact share R = 2 mu^2 R_first, mu scaled by 1/sqrt(impratio) */
   for (int c = 0; c < w->ncon; c++) {
     int e0 = w->con_efc[c];
+    if (m->cone == FMJ_CONE_ELLIPTIC) {
+      /* elliptic: R of friction dimension j = R_normal mu^2 / friction_j^2 with mu = friction_0 / sqrt(impratio): in the
+       * coordinates U_0 = mu jar_0, U_j = friction_j jar_j the regulariser is isotropic and the friction cone is circular */
+      if (e0 + 3 > w->nefc) continue;
+      double mu = w->con_mu[c] / sqrt(m->impratio > 0 ? m->impratio : 1.0), fr = w->con_mu[c];
+      for (int r = 1; r < 3; r++) w->efc_R[e0 + r] = fmax(MINVAL, w->efc_R[e0] * mu * mu / (fr * fr));
+      continue;
+    }
     if (e0 + 4 > w->nefc) continue;
     double mu = w->con_mu[c] / sqrt(m->impratio > 0 ? m->impratio : 1.0);
     double Rpy = 2 * mu * mu * w->efc_R[e0];
     for (int r = 0; r < 4; r++) w->efc_R[e0 + r] = fmax(MINVAL, Rpy);
   }
+}
+
+/* ---- elliptic cone (condim 3), primal side: mj_constraintUpdate's three zones -------------------------------------------
+ * jar = (normal, tangent 1, tangent 2) residuals of one contact; D0 = 1 / R of the normal row, mu = friction / sqrt(impratio),
+ * fr = the friction coefficient of the tangents.  With U_0 = mu jar_0, U_j = fr jar_j, N = U_0, T = |U_1..2| the cost is
+ * D0 / mu^2 times half the squared distance of U to the cone N >= mu T:
+ *   top zone    (N >= mu T):        0, no force
+ *   bottom zone (mu N + T <= 0):    0.5 sum D_j jar_j^2, force_j = -D_j jar_j            (D_j = D0 fr^2 / mu^2 for the tangents)
+ *   middle zone:                    0.5 Dm (N - mu T)^2, Dm = D0 / (mu^2 (1 + mu^2)), force_0 = -Dm (N - mu T) mu,
+ *                                   force_j = -force_0 U_j fr / T
+ * Returns the zone (0 top, 1 bottom, 2 middle); force / hess (3 x 3, d2 cost / d jar2) may be NULL. */
+static int cone_zone(const double* jar, double D0, double mu, double fr, double* cost, double* force, double* hess) {
+  double U[3] = {jar[0] * mu, jar[1] * fr, jar[2] * fr};
+  double N = U[0], T = sqrt(U[1] * U[1] + U[2] * U[2]);
+  if (force) force[0] = force[1] = force[2] = 0;
+  if (hess) memset(hess, 0, 9 * sizeof(double));
+  *cost = 0;
+  if (N >= mu * T || (T <= 0 && N >= 0)) return 0;
+  if (mu * N + T <= 0 || (T <= 0 && N < 0)) {
+    double Dj[3] = {D0, D0 * fr * fr / (mu * mu), D0 * fr * fr / (mu * mu)};
+    for (int j = 0; j < 3; j++) { *cost += 0.5 * Dj[j] * jar[j] * jar[j]; if (force) force[j] = -Dj[j] * jar[j]; if (hess) hess[4 * j] = Dj[j]; }
+    return 1;
+  }
+  double Dm = D0 / (mu * mu * (1 + mu * mu)), NmT = N - mu * T;
+  *cost = 0.5 * Dm * NmT * NmT;
+  if (force) { force[0] = -Dm * NmT * mu; force[1] = -force[0] / T * U[1] * fr; force[2] = -force[0] / T * U[2] * fr; }
+  if (hess) {
+    /* a = d(N - mu T)/d jar; d2 T / d jar_a d jar_b = fr^2 delta_ab / T - fr^4 jar_a jar_b / T^3 on the tangents */
+    double a[3] = {mu, -mu * fr * U[1] / T, -mu * fr * U[2] / T};
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) hess[3 * i + j] = Dm * a[i] * a[j];
+    double k = -Dm * NmT * mu;                      /* > 0 in the middle zone */
+    for (int i = 1; i < 3; i++) for (int j = 1; j < 3; j++)
+      hess[3 * i + j] += k * ((i == j ? fr * fr / T : 0.0) - fr * fr * U[i] * U[j] / (T * T * T));
+  }
+  return 2;
+}
+/* first row of an elliptic contact whose three rows all fit the row budget? */
+static int ell_block(const ws_t* w, int e) {
+  return w->efc_type[e] == EFC_ELLIPTIC && e == w->con_efc[w->efc_id[e]] && e + 3 <= w->nefc;
+}
+/* forces, active states and cost of the constraint part for residuals jar (mj_constraintUpdate): unilateral rows + cones */
+static double rows_update(const fmj_model* m, const ws_t* w, const double* jar, double* force, int* state) {
+  double cost = 0;
+  const double isq = 1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0);
+  for (int e = 0; e < w->nefc; e++) {
+    if (ell_block(w, e)) {
+      double c, f[3]; int c_ = w->efc_id[e];
+      int z = cone_zone(jar + e, 1.0 / w->efc_R[e], w->con_mu[c_] * isq, w->con_mu[c_], &c, f, NULL);
+      cost += c;
+      for (int j = 0; j < 3; j++) { if (force) force[e + j] = f[j]; if (state) state[e + j] = z; }
+      e += 2;
+      continue;
+    }
+    double D = 1.0 / w->efc_R[e];
+    if (jar[e] < 0) { if (force) force[e] = -D * jar[e]; cost += 0.5 * D * jar[e] * jar[e]; if (state) state[e] = 1; }
+    else { if (force) force[e] = 0; if (state) state[e] = 0; }
+  }
+  return cost;
+}
+
+/* mju_QCQP2: min 0.5 x'A x + x'b  s.t.  sum (x_i / d_i)^2 <= r^2, by Newton's method on the multiplier in scaled coordinates.
+ * Returns 1 when the constraint is active. */
+static int qcqp2(double* res, const double A_[4], const double b_[2], const double d[2], double r) {
+  double b1 = b_[0] * d[0], b2 = b_[1] * d[1];
+  double A11 = A_[0] * d[0] * d[0], A22 = A_[3] * d[1] * d[1], A12 = A_[1] * d[0] * d[1];
+  double la = 0, r2 = r * r, v1 = 0, v2 = 0;
+  for (int it = 0; it < 20; it++) {
+    double det = (A11 + la) * (A22 + la) - A12 * A12;
+    if (det < 1e-10) { v1 = v2 = 0; break; }
+    double di = 1 / det, P11 = (A22 + la) * di, P22 = (A11 + la) * di, P12 = -A12 * di;
+    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+    double val = v1 * v1 + v2 * v2 - r2;
+    if (val < 1e-10) break;
+    double deriv = -2 * (P11 * v1 * v1 + 2 * P12 * v1 * v2 + P22 * v2 * v2);
+    double delta = -val / deriv;
+    if (delta < 1e-10) break;
+    la += delta;
+  }
+  res[0] = v1 * d[0]; res[1] = v2 * d[1];
+  return la != 0;
+}
+
+/* one PGS pass over the three rows of an elliptic contact starting at row i (mj_solPGS, elliptic branch): first the whole force
+ * vector of the contact moves along its own ray (or, with no normal force yet, the normal alone moves and friction is cleared),
+ * then the friction forces solve their QCQP inside the cone of the new normal force.  Returns the cost change (<= 0). */
+static double pgs_elliptic_block(const fmj_model* m, ws_t* w, int i) {
+  int n = w->nefc, c = w->efc_id[i];
+  double res[3], A[9], old[3], *f = w->efc_force + i;
+  for (int j = 0; j < 3; j++) {
+    res[j] = w->efc_b[i + j];
+    for (int k = 0; k < n; k++) res[j] += w->efc_AR[(size_t)(i + j) * n + k] * w->efc_force[k];
+    for (int k = 0; k < 3; k++) A[3 * j + k] = w->efc_AR[(size_t)(i + j) * n + i + k];
+    old[j] = f[j];
+  }
+  if (f[0] < MINVAL) {
+    f[0] -= res[0] / A[0]; if (f[0] < 0) f[0] = 0;
+    f[1] = f[2] = 0;
+  } else {
+    double v[3] = {f[0], f[1], f[2]}, v1[3], denom = 0, num = 0;
+    for (int j = 0; j < 3; j++) { v1[j] = A[3 * j] * v[0] + A[3 * j + 1] * v[1] + A[3 * j + 2] * v[2]; }
+    for (int j = 0; j < 3; j++) { denom += v[j] * v1[j]; num += v[j] * res[j]; }
+    if (denom >= MINVAL) {
+      double x = -num / denom;
+      if (f[0] + x * v[0] < 0) x = -f[0] / v[0];
+      for (int j = 0; j < 3; j++) f[j] += x * v[j];
+    }
+  }
+  if (f[0] < MINVAL) f[1] = f[2] = 0;
+  else {
+    double Ac[4] = {A[4], A[5], A[7], A[8]}, bc[2], d[2] = {w->con_mu[c], w->con_mu[c]}, v[2];
+    for (int j = 1; j < 3; j++) bc[j - 1] = res[j] - A[3 * j + 1] * old[1] - A[3 * j + 2] * old[2] + A[3 * j] * (f[0] - old[0]);
+    /* res is the residual at the OLD forces: remove the old friction's share, put the normal's change in */
+    if (qcqp2(v, Ac, bc, d, f[0])) {
+      double s = (v[0] / d[0]) * (v[0] / d[0]) + (v[1] / d[1]) * (v[1] / d[1]);
+      s = sqrt(f[0] * f[0] / fmax(MINVAL, s));
+      v[0] *= s; v[1] *= s;
+    }
+    f[1] = v[0]; f[2] = v[1];
+  }
+  double dl[3] = {f[0] - old[0], f[1] - old[1], f[2] - old[2]}, change = 0;
+  for (int j = 0; j < 3; j++) { change += dl[j] * res[j]; for (int k = 0; k < 3; k++) change += 0.5 * dl[j] * A[3 * j + k] * dl[k]; }
+  if (change > 1e-10) { f[0] = old[0]; f[1] = old[1]; f[2] = old[2]; change = 0; }
+  (void)m;
+  return change;
 }
 
 static double dual_cost(const ws_t* w, const double* f) {
@@ -820,9 +961,11 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
     w->efc_b[i] = dotn(w->efc_J + (size_t)i * nv, w->qacc_smooth, nv) - w->efc_aref[i];
   }
   /* warm start from previous qacc (mj_fwdConstraint) */
-  for (int i = 0; i < n; i++) {
-    double jar = dotn(w->efc_J + (size_t)i * nv, w->qacc_warmstart, nv) - w->efc_aref[i];
-    w->efc_force[i] = jar < 0 ? -jar / w->efc_R[i] : 0.0;
+  {
+    double* jar = dalloc(n);
+    for (int i = 0; i < n; i++) jar[i] = dotn(w->efc_J + (size_t)i * nv, w->qacc_warmstart, nv) - w->efc_aref[i];
+    rows_update(m, w, jar, w->efc_force, NULL);      /* mj_constraintUpdate at the warm start: cone zones for elliptic contacts */
+    free(jar);
   }
   if (dual_cost(w, w->efc_force) > 0) memset(w->efc_force, 0, n * sizeof(double));
   /* PGS (mj_solPGS) */
@@ -830,6 +973,7 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
   for (int it = 0; it < m->solver_iterations; it++) {
     double improvement = 0;
     for (int i = 0; i < n; i++) {
+      if (ell_block(w, i)) { improvement -= pgs_elliptic_block(m, w, i); i += 2; continue; }
       double res = w->efc_b[i];
       for (int j = 0; j < n; j++) res += w->efc_AR[(size_t)i * n + j] * w->efc_force[j];
       double old = w->efc_force[i];
@@ -858,7 +1002,8 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
  * its documentation [MJ-knowledge], not compiled from it).  Reference mjcf.py:1348-1359 forwards
  * simulation_options.solver / n_solver_iters; its own fallback is 'Newton' with 1000 iterations.
  *
- * The problem (pyramidal cone, limits: every row unilateral):
+ * The problem (pyramidal cone, limits: every row unilateral; an elliptic contact replaces its rows' terms by the cone cost of
+ * cone_zone above and its share of the Hessian by J_c' Hc J_c):
  *     minimise over qacc   0.5 (qacc - qacc_smooth)' M (qacc - qacc_smooth) + sum_e s_e(J_e qacc - aref_e),
  *     s_e(x) = 0.5 x^2 / R_e for x < 0, else 0;        force_e = -x / R_e for x < 0, else 0.
  * Its dual is the problem PGS solves (0.5 f'(A + R) f + f'b over f >= 0), so a converged PGS and the Newton minimiser
@@ -889,11 +1034,7 @@ typedef struct primal_t {
 /* mj_constraintUpdate for unilateral rows + the Gauss term: cost, forces, qfrc_constraint, active set */
 static void primal_update(primal_t* P) {
   const fmj_model* m = P->m; ws_t* w = P->w; int nv = P->nv, n = P->n;
-  double cost = 0;
-  for (int e = 0; e < n; e++) {
-    if (P->jar[e] < 0) { P->force[e] = -P->D[e] * P->jar[e]; cost += 0.5 * P->D[e] * P->jar[e] * P->jar[e]; P->state[e] = 1; }
-    else { P->force[e] = 0; P->state[e] = 0; }
-  }
+  double cost = rows_update(m, w, P->jar, P->force, P->state);
   for (int i = 0; i < nv; i++) P->qfc[i] = 0;
   for (int e = 0; e < n; e++) if (P->state[e]) for (int i = 0; i < nv; i++) P->qfc[i] += w->efc_J[(size_t)e * nv + i] * P->force[e];
   double g = 0;
@@ -909,7 +1050,20 @@ static void newton_direction(primal_t* P) {
   double* H = P->H;
   memset(H, 0, (size_t)nv * nv * sizeof(double));
   for (int i = 0; i < nv; i++) { int a = m->dof_Madr[i]; for (int j = i; j >= 0; j = m->dof_parentid[j]) { H[i * nv + j] = H[j * nv + i] = w->qM[a++]; } }
+  const double isq = 1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0);
   for (int e = 0; e < n; e++) if (P->state[e]) {
+    if (ell_block(w, e)) {
+      /* bottom zone: three quadratic rows (their own D); middle zone: J_c' Hc J_c with the 3 x 3 Hessian of the cone */
+      double c, hc[9]; int c_ = w->efc_id[e];
+      cone_zone(P->jar + e, P->D[e], w->con_mu[c_] * isq, w->con_mu[c_], &c, NULL, hc);
+      for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) {
+        if (hc[3 * a + b] == 0) continue;
+        const double *Ja = w->efc_J + (size_t)(e + a) * nv, *Jb = w->efc_J + (size_t)(e + b) * nv;
+        for (int i = 0; i < nv; i++) if (Ja[i] != 0) for (int j = 0; j < nv; j++) H[i * nv + j] += hc[3 * a + b] * Ja[i] * Jb[j];
+      }
+      e += 2;
+      continue;
+    }
     const double* J = w->efc_J + (size_t)e * nv; double d = P->D[e];
     for (int i = 0; i < nv; i++) if (J[i] != 0) for (int j = 0; j < nv; j++) H[i * nv + j] += d * J[i] * J[j];
   }
@@ -933,7 +1087,17 @@ typedef struct ls_pt { double alpha, cost, d0, d1; } ls_pt;
 static ls_pt ls_eval(const primal_t* P, const double* qg, double alpha) {
   ls_pt p; p.alpha = alpha;
   double c = qg[0] + alpha * (qg[1] + alpha * qg[2]), d0 = qg[1] + 2 * alpha * qg[2], d1 = 2 * qg[2];
+  const double isq = 1.0 / sqrt(P->m->impratio > 0 ? P->m->impratio : 1.0);
   for (int e = 0; e < P->n; e++) {
+    if (ell_block(P->w, e)) {
+      double x3[3], cc, f3[3], hc[9]; int c_ = P->w->efc_id[e];
+      for (int j = 0; j < 3; j++) x3[j] = P->jar[e + j] + alpha * P->Jv[e + j];
+      cone_zone(x3, P->D[e], P->w->con_mu[c_] * isq, P->w->con_mu[c_], &cc, f3, hc);
+      c += cc;
+      for (int a = 0; a < 3; a++) { d0 -= f3[a] * P->Jv[e + a]; for (int b = 0; b < 3; b++) d1 += hc[3 * a + b] * P->Jv[e + a] * P->Jv[e + b]; }
+      e += 2;
+      continue;
+    }
     double x = P->jar[e] + alpha * P->Jv[e];
     if (x < 0) { c += 0.5 * P->D[e] * x * x; d0 += P->D[e] * x * P->Jv[e]; d1 += P->D[e] * P->Jv[e] * P->Jv[e]; }
   }
@@ -995,8 +1159,10 @@ static void solve_primal(const fmj_model* m, ws_t* w, int newton) {
   for (int e = 0; e < n; e++) P.jar[e] = dotn(w->efc_J + (size_t)e * nv, P.qacc, nv) - w->efc_aref[e];
   primal_update(&P); cost_ws = P.cost;
   {
-    double cs = 0;
-    for (int e = 0; e < n; e++) { double x = dotn(w->efc_J + (size_t)e * nv, w->qacc_smooth, nv) - w->efc_aref[e]; if (x < 0) cs += 0.5 * P.D[e] * x * x; }
+    double* js = dalloc(n);
+    for (int e = 0; e < n; e++) js[e] = dotn(w->efc_J + (size_t)e * nv, w->qacc_smooth, nv) - w->efc_aref[e];
+    double cs = rows_update(m, w, js, NULL, NULL);
+    free(js);
     if (cost_ws > cs) {
       memcpy(P.qacc, w->qacc_smooth, nv * sizeof(double));
       mul_M_sparse(m, w->qM, P.qacc, P.Ma);
@@ -1298,9 +1464,10 @@ static void export_contacts(const ws_t* w, double* out) {
   for (int c = 0; c < w->ncon; c++) {
     double* o = out + (size_t)FMJO_CONTACT_W * c;
     memcpy(o, w->con_pos + 3 * c, 3 * sizeof(double)); memcpy(o + 3, w->con_frame + 9 * c, 9 * sizeof(double));
-    const double* f = w->efc_force + w->con_efc[c];      /* pyramid edge forces -> contact-frame force */
+    const double* f = w->efc_force + w->con_efc[c];      /* pyramid edge forces -> contact-frame force (mju_decodePyramid) */
     double mu = w->con_mu[c];
-    o[12] = f[0] + f[1] + f[2] + f[3]; o[13] = mu * (f[0] - f[1]); o[14] = mu * (f[2] - f[3]);
+    if (w->efc_type[w->con_efc[c]] == EFC_ELLIPTIC) { o[12] = f[0]; o[13] = f[1]; o[14] = f[2]; }      /* elliptic: the rows are the frame axes */
+    else { o[12] = f[0] + f[1] + f[2] + f[3]; o[13] = mu * (f[0] - f[1]); o[14] = mu * (f[2] - f[3]); }
     o[15] = w->con_plane[c]; o[16] = w->con_geom[c]; o[17] = w->con_dist[c];
   }
 }

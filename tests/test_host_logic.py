@@ -173,8 +173,9 @@ def test_unsupported_solver_options_are_refused():
     check_supported_options(SimulationOptions())
     check_supported_options(SimulationOptions(solver='Newton'))        # round 3: the device has MuJoCo's Newton and CG solvers too
     check_supported_options(SimulationOptions(solver='CG'))
+    check_supported_options(SimulationOptions(solver='Newton', cone='elliptic'))
     check_supported_options(None)
-    for kw in (dict(cone='elliptic'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='SOR')):
+    for kw in (dict(cone='elliptic'), dict(cone='elliptic', solver='PGS'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='SOR')):
         with pytest.raises(NotImplementedError):
             check_supported_options(SimulationOptions(**kw))
 

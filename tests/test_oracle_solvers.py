@@ -8,7 +8,7 @@ import copy
 import numpy as np
 import pytest
 
-from farms_mujoco_amd.model import ModelBuilder, GEOM_PLANE, GEOM_BOX, GEOM_SPHERE, SOLVERS
+from farms_mujoco_amd.model import ModelBuilder, GEOM_PLANE, GEOM_BOX, GEOM_SPHERE, SOLVERS, CONES
 
 
 def _with(m, solver, iterations, tolerance):
@@ -135,3 +135,98 @@ def test_newton_walk_equals_the_converged_pgs_walk(oracle):
     assert np.abs(st['pgs']['qpos'] - st['newton']['qpos']).max() < 1e-6
     assert 1e-4 < np.abs(st['pgs50']['qpos'] - st['newton']['qpos']).max() < 5e-2
     assert st['newton']['qpos'][:, 2].min() > 0.0
+
+
+# ---- elliptic cone (reference mjcf.py:1342-1347 forwards simulation_options.cone) -------------------------------------------
+
+def _cone_kkt(o, e, mu_of_contact):
+    """KKT residuals of the dual cone problem  min 0.5 f'(A + R) f + f'b,  f in K  for env e of a step_tf result: K is f >= 0 for
+    a limit row and f_n >= 0, |f_t| <= mu f_n for the three rows of an elliptic contact; the gradient r = (A + R) f + b must lie in
+    the dual cone (r >= 0; r_n >= mu |r_t|) and be orthogonal to f.  Written from the optimality conditions, not from a solver."""
+    n = int(o['nefc'][e]); f = o['efc'][e, :n, 0]; b = o['efc'][e, :n, 1]; typ = o['efc'][e, :n, 4]; cid = o['efc'][e, :n, 5].astype(int)
+    r = o['AR'][e, :n, :n] @ f + b
+    fs = max(np.abs(f).max(), 1e-3); bs = max(np.abs(b).max(), 1.0)
+    worst = 0.0; i = 0
+    while i < n:
+        if typ[i] == 2:
+            mu = mu_of_contact[cid[i]]
+            ft = np.hypot(f[i+1], f[i+2]); rt = np.hypot(r[i+1], r[i+2])
+            worst = max(worst, -min(f[i], 0.0)/fs, max(ft - mu*f[i], 0.0)/fs, max(mu*rt - r[i], 0.0)/bs, abs(f[i:i+3] @ r[i:i+3])/(fs*bs))
+            i += 3
+        else:
+            worst = max(worst, -min(f[i], 0.0)/fs, -min(r[i], 0.0)/bs, abs(f[i]*r[i])/(fs*bs))
+            i += 1
+    return worst
+
+
+def _elliptic(m, impratio=1.0):
+    m2 = copy.copy(m); m2.cone = CONES['elliptic']; m2.impratio = impratio
+    return m2
+
+
+@pytest.mark.parametrize('impratio', [1.0, 4.0])
+def test_elliptic_newton_cg_and_the_cone_kkt(oracle, impratio):
+    """cone = elliptic: Newton and CG minimise the primal cost with MuJoCo's three cone zones; their forces must satisfy the
+    optimality conditions of the DUAL cone problem built from A, R, b - conditions neither solver ever sees.  PGS (ray update +
+    friction QCQP, mj_solPGS) reaches the same forces wherever it moves at all: from zero force it cannot leave the apex of a
+    cone whose normal residual is positive (its normal-only update clamps to 0 and clears friction) although a friction-bearing
+    force lowers the cost - MuJoCo's PGS has that property, the test counts those contacts instead of hiding them."""
+    total, stalled = 0, 0
+    for mk in (_walker, _box_bot):
+        m = _elliptic(mk(), impratio)
+        n = 6
+        qpos, qvel = _states(m, n, 0, spread=0.1 if mk is _walker else 0.05)
+        if mk is _walker:
+            qpos[:3, 2] = 0.012; qpos[:, 7 + 3] = 1.25
+        else:
+            qpos[:, 2] = 0.047; qpos[:3, 7] = 0.31; qpos[3:, 7] = 0.24
+        qvel[:, :2] += 0.3                                   # sliding: the friction forces sit on the cone
+        ctrl = np.zeros((n, m.nu))
+        a = oracle.step_tf(_with(m, 'pgs', 20000, 0.0), qpos, qvel, ctrl=ctrl)
+        b = oracle.step_tf(_with(m, 'newton', 100, 1e-14), qpos, qvel, ctrl=ctrl)
+        c = oracle.step_tf(_with(m, 'cg', 5000, 1e-16), qpos, qvel, ctrl=ctrl)
+        assert np.array_equal(a['nefc'], b['nefc']) and b['ncon'].min() >= 2
+        assert (b['iterations'] <= 30).all()
+        for e in range(n):
+            ne = int(b['nefc'][e])
+            mus = {}                                          # friction of a contact = max over its two geoms (MuJoCo's rule), floor mjMINMU
+            for k in range(int(b['ncon'][e])):
+                g1, g2 = int(b['contact'][e, k, 15]), int(b['contact'][e, k, 16])
+                mus[k] = max(float(m.geom_friction[g1][0]), float(m.geom_friction[g2][0]), 1e-5)
+            fs = max(np.abs(b['efc'][e, :ne, 0]).max(), 1e-3)
+            assert _cone_kkt(b, e, mus) < 1e-7, (mk.__name__, e, _cone_kkt(b, e, mus))
+            assert np.abs(c['efc'][e, :ne, 0] - b['efc'][e, :ne, 0]).max()/fs < 1e-6
+            total += 1
+            if _cone_kkt(a, e, mus) < 1e-6:                   # PGS converged: the same forces
+                assert np.abs(a['efc'][e, :ne, 0] - b['efc'][e, :ne, 0]).max()/fs < 1e-5
+            else:
+                stalled += 1
+        assert np.abs(c['qvel'] - b['qvel']).max() < 1e-5          # CG stops at ~1e-8 of the forces (weighted as in _agree)
+    print(f'elliptic, impratio {impratio}: PGS stalled at a cone apex in {stalled} of {total} envs')
+    assert total - stalled >= 6
+
+
+def test_elliptic_friction_is_isotropic(oracle):
+    """A ball sliding on the plane without spin: with the elliptic cone the friction force opposes the sliding velocity exactly
+    and has magnitude mu f_n whatever the direction (the pyramidal cone is a square pyramid: direction-dependent)."""
+    b = ModelBuilder('ball', timestep=1e-3)
+    b.add_body('ball', 'world', pos=(0, 0, 0.0495), mass=0.5, inertia=(5e-4, 5e-4, 5e-4), joint='free')
+    b.add_geom('ball', GEOM_SPHERE, (0.05,), friction=(0.6, 0, 0))
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0.6, 0, 0))
+    b.options['max_contacts'] = 4
+    m = b.compile()
+    for cone, tol in (('elliptic', 1e-9), ('pyramidal', None)):
+        mm = copy.copy(m); mm.cone = CONES[cone]
+        ratios, angles = [], []
+        for th in np.linspace(0.1, 1.4, 6):
+            qpos = m.qpos0[None].copy(); qvel = np.zeros((1, m.nv)); qvel[0, 0] = 1.0*np.cos(th); qvel[0, 1] = 1.0*np.sin(th)
+            o = oracle.step_tf(_with(mm, 'newton', 100, 1e-14), qpos, qvel)
+            assert o['ncon'][0] == 1
+            fn, f1, f2 = o['contact'][0, 0, 12:15]; fr = o['contact'][0, 0, 3:12].reshape(3, 3)
+            ft = f1*fr[1] + f2*fr[2]                              # world-frame friction on the ball
+            ratios.append(np.linalg.norm(ft)/fn)
+            angles.append(np.arctan2(-ft[1], -ft[0]) - th)
+        if cone == 'elliptic':
+            assert np.abs(np.array(ratios) - 0.6).max() < tol and np.abs(angles).max() < 1e-9, (ratios, angles)
+        else:
+            assert np.ptp(ratios) > 0.05                          # the pyramid's friction limit depends on the direction
