@@ -1751,6 +1751,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 7) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true, true, true>;
   if (cons == 6) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true, true>;
   if (cons == 5) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true>;
   if (cons == 4) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true>;
@@ -1891,7 +1892,7 @@ extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes)
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes), 7 Newton / CG + explicit pairs (+ meshes)
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -1906,7 +1907,7 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.cone == FMJ_CONE_ELLIPTIC ? 6 : (c->dm.any_mesh ? 5 : 3)) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.cone == FMJ_CONE_ELLIPTIC ? 6 : (c->dm.npair > 0 ? 7 : (c->dm.any_mesh ? 5 : 3))) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
@@ -2000,7 +2001,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
   if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON && m->solver != FMJ_SOLVER_CG) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: solver must be FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON");
-  if (cons && m->solver != FMJ_SOLVER_PGS && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the Newton / CG solvers of the HIP path cover limits and ground contacts (the Hessian M + J'DJ keeps the tree sparsity of M only when every row touches one chain): no explicit pairs");
+  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path covers limits and ground contacts: no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG (the PGS kernel implements the pyramidal cone only)");
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");

@@ -184,8 +184,8 @@ typedef struct fmj_model {
   double solver_tolerance;
   double meaninertia;           /* mjModel.stat.meaninertia: mean diagonal of M at qpos0 (solver termination scale) */
   /* ABI 4 */
-  int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353).  HIP path: PGS (any model of the subset), Newton or CG
-                                   (limits + ground contacts, mesh geoms included: no explicit pairs) */
+  int32_t solver;               /* FMJ_SOLVER_*: option.solver (mjcf.py:1348-1353).  HIP path: PGS, Newton or CG on any model of the subset; under
+                                   Newton / CG an env with an ACTIVE explicit-pair contact is solved on the dual problem (PGS to tolerance) */
   int32_t cone;                 /* FMJ_CONE_*:   option.cone   (mjcf.py:1342-1347).  HIP path: pyramidal with any solver, elliptic with
                                    Newton / CG (three rows per contact in fmj_step_debug's rows; maxefc stays the 4-per-contact bound) */
   int32_t ls_iterations;        /* Newton / CG line-search iterations (MuJoCo option.ls_iterations, default 50); <= 0: 50 */

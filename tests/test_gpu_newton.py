@@ -120,13 +120,92 @@ def test_newton_with_mesh_feet_on_a_heightfield(oracle):
     assert e.max() < 1e-3
 
 
-def test_newton_and_cg_refused_for_pairs():
-    from farms_mujoco_amd.model import salamander33, SOLVERS
+@pytest.mark.parametrize('solver', ['newton', 'cg'])
+def test_newton_and_cg_with_self_collision_pairs(oracle, solver):
+    """Explicit pairs (reference mjcf.py:1012-1033, declared with friction 0) under the primal solvers.  Their rows carry R ~ 1e-10 R0: a
+    1 N force is a residual of 1e-11, which no fp32 primal iteration resolves, so an env whose step has an ACTIVE pair contact is
+    solved on the dual problem (PGS to the solver's tolerance): same convex problem, same minimiser; the oracle runs the solver
+    that was asked for, in fp64 - except that the reference solution is always the Newton minimiser: the oracle's own CG, capped at
+    100 iterations, does not get through rows with D = 4e10 (it ends 0.6 of the largest force away from the minimiser).  Scissors (one pair row set, nothing else) and the
+    salamander lying on the plane with feet meeting under the trunk / head meeting tail: forces and velocity of one step, then 40 steps."""
+    import torch
+    from farms_mujoco_amd.model import SOLVERS
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from test_oracle_contacts import _scissors
+    from test_gpu_contacts import _salamander_self_collisions
+    for capsule in (False, True):
+        m, q = _scissors(0.1, capsule=capsule)
+        m.solver = SOLVERS[solver]; m.solver_iterations = 100
+        mo = copy.copy(m); mo.solver = SOLVERS['newton']
+        n = 6
+        rng = np.random.default_rng(3)
+        qpos = np.tile(q, (n, 1)) + rng.uniform(-0.03, 0.03, (n, 2)); qpos[n - 1] = [0.6, -0.6]
+        phys = BatchedPhysics(m, n)
+        q32, v32, _ = _set(phys, qpos, rng.normal(size=(n, 2))*0.2)
+        phys.step(1)
+        torch.cuda.synchronize()
+        d = phys.data
+        o = oracle.step_tf(mo, q32, v32, ctrl=np.zeros((n, m.nu)), want_AR=False)
+        assert int(d.status.abs().sum()) == 0 and np.array_equal(d.ncon.cpu().numpy(), o['ncon']) and o['ncon'][:-1].min() == 1
+        con = oracle.contacts_from_hip(d.contact.cpu().numpy())
+        assert np.abs(con[:n-1, 0, 12] - o['contact'][:n-1, 0, 12]).max() < 1e-3*np.abs(o['contact'][:n-1, 0, 12]).max()
+        assert np.abs(d.qvel.cpu().numpy() - o['qvel']).max() < 1e-4*np.abs(o['qvel']).max()
+        phys.step(199)
+        torch.cuda.synchronize()
+        ref = oracle.step(mo, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=200)
+        assert int(d.status.abs().sum()) == 0 and np.abs(d.qpos.cpu().numpy() - ref['qpos']).max() < 2e-4
+    m = _salamander_self_collisions()
+    m.solver = SOLVERS[solver]; m.solver_iterations = 100
+    mo = copy.copy(m); mo.solver = SOLVERS['newton']
+    plane = int(np.nonzero(m.geom_type == 0)[0][0])
+    spine = [m.jnt_qposadr[m.joint_names.index(f'joint_body_{i}')] for i in range(1, 12)]
+    legj = [m.jnt_qposadr[m.joint_names.index(f'joint_leg_{t}_{s_}_{k}')] for t in ('front', 'hind') for s_ in ('L', 'R') for k in range(4)]
+    poses = []
+    for legs in ([-1.19, 0.07, -0.84, -0.74, 0.24, -0.09, 1.01, -0.27, 0.42, -0.19, 0.52, -0.12, -0.63, 0.83, 0.69, -0.46],
+                 [-0.25, -0.11, 0.59, -0.16, 1.02, 0.67, 0.77, -0.62, -0.01, -0.32, -0.9, 0.36, 0.78, 0.27, 1.14, -0.7]):
+        q = m.qpos0.copy(); q[2] = 0.05; q[legj] = legs; poses.append(q)
+    for curl in (0.645, 0.65):
+        q = m.qpos0.copy(); q[2] = 0.03; q[spine] = curl; poses.append(q)
+    q = m.qpos0.copy(); q[2] = 0.045; poses.append(q)                     # a fifth env without self-contact: takes the solver that was asked for
+    qpos = np.array(poses); n = len(poses)
+    rng = np.random.default_rng(21)
+    phys = BatchedPhysics(m, n)
+    q32, v32, w32 = _set(phys, qpos, 0.02*rng.normal(size=(n, m.nv)))
+    phys.step_debug(want_pgs=False)
+    torch.cuda.synchronize()
+    d = phys.data
+    o = oracle.step_tf(mo, q32, v32, ctrl=np.zeros((n, m.nu)), warmstart=w32, want_AR=False)
+    assert int(d.status.abs().sum()) == 0 and np.array_equal(d.ncon.cpu().numpy(), o['ncon'])
+    npair = [(o['contact'][e, :o['ncon'][e], 15] != plane).sum() for e in range(n)]
+    assert min(npair[:4]) >= 1 and npair[4] == 0
+    # contact-frame forces, not rows: the four pyramid edges of a friction-0 pair (mu = 1e-5) are the same row to 1e-5, their sum is
+    # determined, its split among them is not
+    con = oracle.contacts_from_hip(d.contact.cpu().numpy())
+    worst = 0.0
+    for e in range(n):
+        nc = int(o['ncon'][e])
+        if nc:
+            fs = max(np.abs(o['contact'][e, :nc, 12]).max(), 1e-2)
+            worst = max(worst, np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max()/fs)
+    err = group_relerr(d.qvel.cpu().numpy(), o['qvel'], qvel_groups(m))
+    print(solver, 'with self-collision pairs: contact-frame forces', worst, 'qvel per component', err)
+    assert worst < 3e-3 and err < 3e-2
+    phys.step(39)
+    torch.cuda.synchronize()
+    ref = oracle.step(mo, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=40, n_threads=8)
+    assert int(d.status.abs().sum()) == 0
+    e40 = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print('  qpos abs err after 40 steps', e40)
+    assert e40.max() < 2e-3 and np.median(e40) < 3e-4
+
+
+def test_elliptic_cone_refused_with_pgs_and_with_pairs():
+    from farms_mujoco_amd.model import salamander33, SOLVERS, CONES
     from farms_mujoco_amd.physics import BatchedPhysics
     from farms_mujoco_amd._lib import FmjError
-    for solver in ('newton', 'cg'):
-        m = salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=True)
-        m.solver = SOLVERS[solver]
+    for solver, kw in (('pgs', {}), ('newton', dict(self_collisions=True))):
+        m = salamander33(contacts=True, limits=True, spawn_z=0.045, **kw)
+        m.solver = SOLVERS[solver]; m.cone = CONES['elliptic']
         with pytest.raises(FmjError):
             BatchedPhysics(m, 2)
 

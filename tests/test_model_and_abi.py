@@ -145,7 +145,7 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     rc, msg = create(m)
     assert rc == 2 and 'FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True, self_collisions=True)
-    m.solver = SOLVERS['newton']
+    m.solver = SOLVERS['newton']; m.cone = 1
     rc, msg = create(m)
     assert rc == 2 and 'no explicit pairs' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True)
