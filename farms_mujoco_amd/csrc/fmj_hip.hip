@@ -2004,6 +2004,15 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path covers limits and ground contacts: no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG (the PGS kernel implements the pyramidal cone only)");
+  if (cons && m->solver != FMJ_SOLVER_PGS && m->cone == FMJ_CONE_PYRAMIDAL && nplane > 0) {
+    // pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 a contact force is a residual too small for an fp32 primal iteration (see
+    // fmj_cons_rows.inc on the friction-0 pairs); ground contacts have no dual fallback in the Newton kernels, so say so here
+    double gmu = 0;
+    for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] == FMJ_GEOM_PLANE || m->geom_type[g] == FMJ_GEOM_HFIELD) gmu = std::max(gmu, m->geom_friction[3 * g]);
+    for (int g = 0; g < m->ngeom; g++)
+      if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) < 1e-3)
+        return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: Newton / CG with the pyramidal cone need ground-contact friction >= 1e-3 in fp32 (R = 2 mu^2 R0 makes the rows too stiff below that): use solver = PGS, the elliptic cone, or give the geoms friction");
+  }
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");

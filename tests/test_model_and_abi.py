@@ -149,6 +149,10 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     rc, msg = create(m)
     assert rc == 2 and 'no explicit pairs' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True)
+    m.solver = SOLVERS['newton']; m.geom_friction = m.geom_friction*0.0
+    rc, msg = create(m)
+    assert rc == 2 and 'friction >= 1e-3' in msg, (rc, msg)
+    m = salamander33(contacts=True, limits=True)
     m.cone = 1
     rc, msg = create(m)
     assert rc == 2 and 'pyramidal' in msg, (rc, msg)
