@@ -319,3 +319,50 @@ def test_elliptic_cone_teacher_forced_per_step(oracle):
     assert flips <= 0.002*n*T and cone_rows > 3*n*T
     assert np.median(ef) < 5e-5 and ef.max() < 1e-3
     assert np.median(ev) < 1e-4 and ev.max() < 2e-3
+
+
+@pytest.mark.parametrize('seed', range(100, 108))
+@pytest.mark.parametrize('solver,cone', [('newton', 'pyramidal'), ('cg', 'pyramidal'), ('newton', 'elliptic')])
+def test_primal_solvers_on_random_contact_trees(oracle, seed, solver, cone):
+    """Random trees (limited hinges, sphere / capsule / box / cylinder geoms over a plane that cuts through the tree) under Newton, CG
+    and the elliptic cone: contact lists, contact-frame forces and velocity of one step against the oracle's Newton minimiser (the
+    oracle's CG, capped at 100 iterations, is itself only within ~1e-4 of it on some of these trees)."""
+    import torch
+    from farms_mujoco_amd.model import SOLVERS, CONES
+    from farms_mujoco_amd.physics import BatchedPhysics
+    from test_gpu_random_trees import random_tree, FMJ_WARN_CONTACTFULL
+    m = random_tree(seed, contacts=True)
+    if m is None or m.nv == 0:
+        pytest.skip('degenerate draw')
+    m.solver = SOLVERS[solver]; m.cone = CONES[cone]; m.solver_iterations = 100
+    mo = copy.copy(m); mo.solver = SOLVERS['newton']
+    rng = np.random.default_rng(2000 + seed)
+    n = 6
+    qpos = np.tile(m.qpos0, (n, 1)) + rng.uniform(-0.4, 0.4, (n, m.nq))
+    for j in range(m.njnt):
+        if m.jnt_type[j] == 0:
+            a = m.jnt_qposadr[j]; q = rng.normal(size=(n, 4)); qpos[:, a+3:a+7] = q/np.linalg.norm(q, axis=1, keepdims=True)
+            qpos[:, a+2] = rng.uniform(-0.05, 0.1, n)
+    qvel = rng.normal(size=(n, m.nv))*0.2
+    ctrl = rng.uniform(-0.4, 0.4, (n, max(m.nu, 1)))[:, :m.nu]
+    phys = BatchedPhysics(m, n)
+    d = phys.data
+    q32, v32, w32 = _set(phys, qpos, qvel)
+    if m.nu:
+        d.ctrl[:] = torch.as_tensor(ctrl, dtype=torch.float32)
+    c32 = d.ctrl.cpu().numpy().astype(np.float64) if m.nu else None
+    phys.step(1)
+    torch.cuda.synchronize()
+    assert int((d.status & ~FMJ_WARN_CONTACTFULL).abs().sum()) == 0
+    o = oracle.step_tf(mo, q32, v32, ctrl=c32, warmstart=w32, want_AR=False)
+    assert np.array_equal(d.ncon.cpu().numpy(), o['ncon'])
+    if o['nefc'].max() == 0:
+        pytest.skip('no active constraint in this draw')
+    con = oracle.contacts_from_hip(d.contact.cpu().numpy())
+    for e in range(n):
+        nc = int(o['ncon'][e])
+        if nc:
+            fs = max(np.abs(o['contact'][e, :nc, 12:15]).max(), 1e-2)
+            assert np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max() < 2e-2*fs + 2e-3, (seed, e, con[e, :nc, 12:15], o['contact'][e, :nc, 12:15])
+    ev = np.abs(d.qvel.cpu().numpy() - o['qvel']).max()/max(np.abs(o['qvel']).max(), 1e-9)
+    assert ev < 3e-3, (seed, m.nbody, m.nv, ev)
