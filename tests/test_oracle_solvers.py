@@ -230,3 +230,36 @@ def test_elliptic_friction_is_isotropic(oracle):
             assert np.abs(np.array(ratios) - 0.6).max() < tol and np.abs(angles).max() < 1e-9, (ratios, angles)
         else:
             assert np.ptp(ratios) > 0.05                          # the pyramid's friction limit depends on the direction
+
+
+def test_sliding_slab_obeys_coulomb_momentum_balance(oracle):
+    """A slab sliding down an incline from rest (tan(theta) > mu; the incline is a tilted gravity).  Whatever the contacts do in
+    between - the four corner contacts chatter - the step is an exact impulse balance, and while sliding every contact obeys
+    |f_t| = mu f_n: so the mean acceleration along the slope over a window is  g sin(theta) - mu (g cos(theta) + dv_z / T)  with
+    dv_z the change of the normal velocity over the window.  Elliptic cone: exact down the slope whatever its heading in the contact
+    frame (1e-6 along a frame axis; 1e-3 at 0.5 rad, where the rocking slab's corner velocities are not exactly parallel to the
+    CoM's); pyramidal cone: exact only along a frame axis, 20 % off at 0.5 rad - the square pyramid is not isotropic."""
+    th, mu, g = 0.5, 0.3, 9.81
+    out = {}
+    for yaw in (0.0, 0.5):
+        b = ModelBuilder('slab', timestep=1e-3, gravity=(g*np.sin(th)*np.cos(yaw), g*np.sin(th)*np.sin(yaw), -g*np.cos(th)))
+        b.add_body('slab', 'world', pos=(0, 0, 0.02), mass=1.0, inertia=(4e-3, 4e-3, 8e-3), joint='free')
+        b.add_geom('slab', GEOM_BOX, (0.1, 0.1, 0.02), friction=(mu, 0, 0))
+        b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(mu, 0, 0))
+        b.options['max_contacts'] = 8
+        m = b.compile()
+        for cone in ('elliptic', 'pyramidal'):
+            mm = _with(m, 'newton', 100, 1e-10); mm.cone = CONES[cone]
+            q = m.qpos0[None].copy(); v = np.zeros((1, m.nv)); w = np.zeros((1, m.nv))
+            vs = []
+            for t in range(1000):
+                o = oracle.step_tf(mm, q, v, warmstart=w, want_AR=False)
+                q, v, w = o['qpos'], o['qvel'], o['warmstart']; vs.append(v[0, :3].copy())
+            a = (vs[999] - vs[199])/0.8
+            along = a[0]*np.cos(yaw) + a[1]*np.sin(yaw); across = -a[0]*np.sin(yaw) + a[1]*np.cos(yaw)
+            out[cone, yaw] = (along, across, g*np.sin(th) - mu*(g*np.cos(th) + a[2]))
+    for (cone, yaw), (along, across, want) in out.items():
+        print(f'{cone:9s} heading {yaw}: along {along:.6f} expected {want:.6f} across {across:.2e}')
+    assert abs(out['elliptic', 0.0][0] - out['elliptic', 0.0][2]) < 1e-6*g and abs(out['pyramidal', 0.0][0] - out['pyramidal', 0.0][2]) < 1e-6*g
+    assert abs(out['elliptic', 0.5][0] - out['elliptic', 0.5][2]) < 2e-3*out['elliptic', 0.5][2] and abs(out['elliptic', 0.5][1]) < 1e-3
+    assert abs(out['pyramidal', 0.5][0] - out['pyramidal', 0.5][2]) > 0.1*out['pyramidal', 0.5][2]
