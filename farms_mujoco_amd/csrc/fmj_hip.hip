@@ -553,16 +553,19 @@ __device__ __forceinline__ void pk_fnma(f2_t& acc, const f2_t tt, const f2_t v) 
 }
 template <int MAXD>
 __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth,
-                                           f2_t (&r)[MAXD / 2], float diag, float& dinv_mine) {
+                                           f2_t (&r)[MAXD / 2], float diag, float& dinv_mine, float& x) {
   constexpr int RS = MAXD;
   // r = the lane's row in registers as float pairs (the update is v_pk_fma_f32), diag its diagonal entry (M phase)
   // Rounds of unrelated dofs (same depth, deepest level first, <= 3 per round; records built at fmj_create and read
   // through the scalar cache one round ahead): every lane publishes its working row and 1/diag (DV) - only the
   // members' are read, theirs are final - and every proper ancestor i of a member k (uniform lane mask) does
   // row_i -= (row_k[depth_i] / D_k) row_k.  One LDS round trip per tree level instead of one per dof.
+  // x: a right-hand side whose leaves-first sweep rides in the rounds (when dof k is a pivot its x_k is complete: every proper
+  // ancestor i does x_i -= L[k][i] x_k next to its row update); on return x holds L^-T-swept rhs, to be scaled by 1 / D and pulled.
+  // A pivot at depth d has entries in slots 0 .. d - 1 only, so a round publishes, reads and applies ceil(d / 4) float4 groups:
+  // one loop per group count, run one after the other (rounds come deepest level first).
+  (void)maxdep;
   const cround_p RND = (cround_p)rounds;
-  // NG_ float4 groups of a row are published, read and applied: ancestors only own slots below the deepest depth, so
-  // when that depth leaves the last group empty the loop runs on MAXD / 4 - 1 groups.
 #define APPLY_PIVOT(NG_, p_, am_) do { \
     const float tk_ = HR[(p_) * RS + ddepth]; const float dki_ = DV[p_]; \
     float4 rk_[NG_]; \
@@ -572,26 +575,40 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
     _Pragma("unroll") for (int g = 0; g < NG_; g++) { \
       pk_fnma(r[2 * g], tt_, f2_t{rk_[g].x, rk_[g].y}); \
       pk_fnma(r[2 * g + 1], tt_, f2_t{rk_[g].z, rk_[g].w}); } \
-    diag = fmaf(-t_, tk_, diag); } while (0)
-#define L_ROUNDS(NG_) do { \
-    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2; \
-    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2]; \
-    _Pragma("unroll 1") for (int rd = 0; rd < nround; rd++) { \
+    diag = fmaf(-t_, tk_, diag); \
+    x = fmaf(-t_, bcast(x, p_), x); } while (0)
+#define ROUND_BODY(NG_) do { \
+    if (isd) { \
+      _Pragma("unroll") for (int d = 0; d < 4 * NG_; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y); \
+      DV[lane] = __builtin_amdgcn_rcpf(diag); \
+    } \
+    WSYNC(); \
+    APPLY_PIVOT(NG_, p0, a0); \
+    if (p1 >= 0) { APPLY_PIVOT(NG_, p1, a1); APPLY_PIVOT(NG_, p2, a2); } \
+    WSYNC(); } while (0)
+  {
+    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2, dep = RND[0].depth;
+    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
+    int rd = 0;
+#define ROUNDS_AT(NG_, COND_) \
+    _Pragma("unroll 1") while (rd < nround && (COND_)) { \
       const int rn = rd + 1 < nround ? rd + 1 : rd; \
-      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2; \
+      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2, ndep = RND[rn].depth; \
       const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2]; \
-      if (isd) { \
-        _Pragma("unroll") for (int d = 0; d < 4 * NG_; d += 4) *(float4*)(HR + lane * RS + d) = make_float4(r[d / 2].x, r[d / 2].y, r[d / 2 + 1].x, r[d / 2 + 1].y); \
-        DV[lane] = __builtin_amdgcn_rcpf(diag); \
-      } \
-      WSYNC(); \
-      APPLY_PIVOT(NG_, p0, a0); \
-      if (p1 >= 0) { APPLY_PIVOT(NG_, p1, a1); APPLY_PIVOT(NG_, p2, a2); } \
-      WSYNC(); \
-      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; \
-    } } while (0)
-  if (MAXD > 4 && maxdep <= MAXD - 4) L_ROUNDS((MAXD > 4 ? MAXD / 4 - 1 : 1)); else L_ROUNDS(MAXD / 4);
-#undef L_ROUNDS
+      ROUND_BODY(NG_); \
+      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; dep = ndep; rd++; \
+    }
+    if (MAXD >= 32) ROUNDS_AT((MAXD >= 32 ? 8 : 1), dep > 28)
+    if (MAXD >= 28) ROUNDS_AT((MAXD >= 28 ? 7 : 1), dep > 24)
+    if (MAXD >= 24) ROUNDS_AT((MAXD >= 24 ? 6 : 1), dep > 20)
+    if (MAXD >= 20) ROUNDS_AT((MAXD >= 20 ? 5 : 1), dep > 16)
+    if (MAXD >= 16) ROUNDS_AT((MAXD >= 16 ? 4 : 1), dep > 12)
+    if (MAXD >= 12) ROUNDS_AT((MAXD >= 12 ? 3 : 1), dep > 8)
+    if (MAXD >= 8) ROUNDS_AT((MAXD >= 8 ? 2 : 1), dep > 4)
+    ROUNDS_AT(1, true)
+#undef ROUNDS_AT
+  }
+#undef ROUND_BODY
 #undef APPLY_PIVOT
   dinv_mine = isd ? __builtin_amdgcn_rcpf(diag) : 0.f;
   // every lane's register row is final since its own round: publish it once more, scaled by 1/D, so that
@@ -1666,9 +1683,11 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     float my_qacc;
     {
       if (CONS) dinv_h = isd ? XV[lane] : 0.f;          // factored together with M
-      else ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, hrow, hdg_h, dinv_h);
+      float xr = isd ? qfrc : 0.f;                        // non-CONS: the right-hand side rides in the rounds of the factorisation
+      if (!CONS) ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, hrow, hdg_h, dinv_h, xr);
       STAMP(9);   // L
-      my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_h, M.ancl1, M.maxdep1);
+      if (CONS) my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_h, M.ancl1, M.maxdep1);
+      else my_qacc = ldl_pull_sweep<MAXD>(HR, xr * dinv_h, isd ? lane : 0, isd, ddepth, M.ancl1, M.maxdep1);
     }
     STAMP(10);  // X
     // ---- semi-implicit Euler (mj_Euler with implicit joint damping)

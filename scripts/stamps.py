@@ -9,7 +9,7 @@ names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L'
          'A|nwt-start', 'warm|nwt-H', 'PGS|nwt-update', 'qfrc_c', 'nwt-factor', 'nwt-solve', 'nwt-linesearch']
 workload = os.environ.get('FMJ_WORKLOAD', 'swim')
 for n in (int(a) for a in sys.argv[1:] or ['256', '4096']):
-    sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
+    sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload, **({'morphology': os.environ['FMJ_MORPHOLOGY']} if 'FMJ_MORPHOLOGY' in os.environ else {}))
     print('lds bytes per env', sim.physics.kernel_info())
     for _ in range(int(os.environ.get('FMJ_STAMP_WARM', '100')) // 100 + 1):
         sim.step_fused(100)
