@@ -55,6 +55,13 @@ struct DualRound {
   unsigned long long desc[3];         // lanes whose dof is a proper descendant of p_c
 };
 
+// The same for ldl_factor of the one-env kernel: up to SIX dofs of a level per round (a centipede has five per level: one round
+// trip per level instead of two); members beyond np repeat p[0] under empty masks and are skipped three at a time.
+struct WideRound {
+  int p[6], depth, np;
+  unsigned long long anc[6];
+};
+
 struct DevModel {
   int nbody, nv, nq, nu, njnt, nM;
   int max_bdepth;     // pointer-jumping rounds = ceil(log2(longest root->body chain))
@@ -98,6 +105,8 @@ struct DevModel {
   int dual_nround;
   const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
   int nround1;
+  const struct WideRound* rounds6;     // [nround6] up to six dofs per round (ldl_factor)
+  int nround6;
   const uint32_t* ancl1;               // [64][rs / 4] the same table for the one-env kernel (lane = dof)
   int maxdep1;                         // deepest dof depth
   const uint32_t* dual_ancl;           // [32][rs / 4] per lane dof: 4 * (lane of its ancestor at each absolute depth), own lane elsewhere
@@ -552,11 +561,11 @@ __device__ __forceinline__ void pk_fnma(f2_t& acc, const f2_t tt, const f2_t v) 
   asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]" : "+v"(acc) : "v"(tt), "v"(v));
 }
 template <int MAXD>
-__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth,
+__device__ __forceinline__ void ldl_factor(float* HR, float* DV, const WideRound* rounds, int nround, int maxdep, int lane, bool isd, int ddepth,
                                            f2_t (&r)[MAXD / 2], float diag, float& dinv_mine, float& x) {
   constexpr int RS = MAXD;
   // r = the lane's row in registers as float pairs (the update is v_pk_fma_f32), diag its diagonal entry (M phase)
-  // Rounds of unrelated dofs (same depth, deepest level first, <= 3 per round; records built at fmj_create and read
+  // Rounds of unrelated dofs (same depth, deepest level first, <= 6 per round; records built at fmj_create and read
   // through the scalar cache one round ahead): every lane publishes its working row and 1/diag (DV) - only the
   // members' are read, theirs are final - and every proper ancestor i of a member k (uniform lane mask) does
   // row_i -= (row_k[depth_i] / D_k) row_k.  One LDS round trip per tree level instead of one per dof.
@@ -565,7 +574,8 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
   // A pivot at depth d has entries in slots 0 .. d - 1 only, so a round publishes, reads and applies ceil(d / 4) float4 groups:
   // one loop per group count, run one after the other (rounds come deepest level first).
   (void)maxdep;
-  const cround_p RND = (cround_p)rounds;
+  typedef const WideRound __attribute__((address_space(4)))* wround_p;
+  const wround_p RND = (wround_p)rounds;
 #define APPLY_PIVOT(NG_, p_, am_) do { \
     const float tk_ = HR[(p_) * RS + ddepth]; const float dki_ = DV[p_]; \
     float4 rk_[NG_]; \
@@ -584,19 +594,20 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const DualRound
     } \
     WSYNC(); \
     APPLY_PIVOT(NG_, p0, a0); \
-    if (p1 >= 0) { APPLY_PIVOT(NG_, p1, a1); APPLY_PIVOT(NG_, p2, a2); } \
+    if (np > 1) { APPLY_PIVOT(NG_, p1, a1); APPLY_PIVOT(NG_, p2, a2); } \
+    if (np > 3) { APPLY_PIVOT(NG_, p3, a3); APPLY_PIVOT(NG_, p4, a4); APPLY_PIVOT(NG_, p5, a5); } \
     WSYNC(); } while (0)
   {
-    int p0 = RND[0].p0, p1 = RND[0].p1, p2 = RND[0].p2, dep = RND[0].depth;
-    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2];
+    int p0 = RND[0].p[0], p1 = RND[0].p[1], p2 = RND[0].p[2], p3 = RND[0].p[3], p4 = RND[0].p[4], p5 = RND[0].p[5], dep = RND[0].depth, np = RND[0].np;
+    unsigned long long a0 = RND[0].anc[0], a1 = RND[0].anc[1], a2 = RND[0].anc[2], a3 = RND[0].anc[3], a4 = RND[0].anc[4], a5 = RND[0].anc[5];
     int rd = 0;
 #define ROUNDS_AT(NG_, COND_) \
     _Pragma("unroll 1") while (rd < nround && (COND_)) { \
       const int rn = rd + 1 < nround ? rd + 1 : rd; \
-      const int np0 = RND[rn].p0, np1 = RND[rn].p1, np2 = RND[rn].p2, ndep = RND[rn].depth; \
-      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2]; \
+      const int np0 = RND[rn].p[0], np1 = RND[rn].p[1], np2 = RND[rn].p[2], np3 = RND[rn].p[3], np4 = RND[rn].p[4], np5 = RND[rn].p[5], ndep = RND[rn].depth, nnp = RND[rn].np; \
+      const unsigned long long na0 = RND[rn].anc[0], na1 = RND[rn].anc[1], na2 = RND[rn].anc[2], na3 = RND[rn].anc[3], na4 = RND[rn].anc[4], na5 = RND[rn].anc[5]; \
       ROUND_BODY(NG_); \
-      p0 = np0; p1 = np1; p2 = np2; a0 = na0; a1 = na1; a2 = na2; dep = ndep; rd++; \
+      p0 = np0; p1 = np1; p2 = np2; p3 = np3; p4 = np4; p5 = np5; a0 = na0; a1 = na1; a2 = na2; a3 = na3; a4 = na4; a5 = na5; dep = ndep; np = nnp; rd++; \
     }
     if (MAXD >= 32) ROUNDS_AT((MAXD >= 32 ? 8 : 1), dep > 28)
     if (MAXD >= 28) ROUNDS_AT((MAXD >= 28 ? 7 : 1), dep > 24)
@@ -1684,7 +1695,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
     {
       if (CONS) dinv_h = isd ? XV[lane] : 0.f;          // factored together with M
       float xr = isd ? qfrc : 0.f;                        // non-CONS: the right-hand side rides in the rounds of the factorisation
-      if (!CONS) ldl_factor<MAXD>(HR, XV, M.rounds1, M.nround1, M.maxdep1, lane, isd, ddepth, hrow, hdg_h, dinv_h, xr);
+      if (!CONS) ldl_factor<MAXD>(HR, XV, M.rounds6, M.nround6, M.maxdep1, lane, isd, ddepth, hrow, hdg_h, dinv_h, xr);
       STAMP(9);   // L
       if (CONS) my_qacc = ldl_solve<MAXD>(HR, qfrc + qfrc_c, lane, isd, ddepth, dsub, nv, dinv_h, M.ancl1, M.maxdep1);
       else my_qacc = ldl_pull_sweep<MAXD>(HR, xr * dinv_h, isd ? lane : 0, isd, ddepth, M.ancl1, M.maxdep1);
@@ -2342,6 +2353,22 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       }
       D.nround1 = (int)rounds.size();
       UP(rounds, rounds1);
+      std::vector<WideRound> wide;                  // the same levels, up to six dofs per round
+      for (int dep = maxdep; dep >= 0; dep--) {
+        std::vector<int> lvl;
+        for (int i = 0; i < nv; i++) if (ddepth[i] == dep) lvl.push_back(i);
+        for (size_t q = 0; q < lvl.size(); q += 6) {
+          WideRound R; memset(&R, 0, sizeof R);
+          R.depth = dep; R.np = (int)std::min<size_t>(6, lvl.size() - q);
+          for (int c = 0; c < 6; c++) {
+            if (q + c < lvl.size()) { R.p[c] = lvl[q + c]; R.anc[c] = ancm[lvl[q + c]]; }
+            else R.p[c] = lvl[q];                   // under an empty mask
+          }
+          wide.push_back(R);
+        }
+      }
+      D.nround6 = (int)wide.size();
+      UP(wide, rounds6);
       {   // per dof, per depth: byte = 4 * lane of the ancestor at that depth (own lane where there is none)
         std::vector<uint32_t> ancl((size_t)64 * (D.rs / 4), 0u);
         for (int i = 0; i < 64; i++) {
