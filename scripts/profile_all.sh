@@ -9,4 +9,6 @@ WARMUP=1000 scripts/profile.sh ${t}_walk_pairs --workload walk_pairs --min-secon
 WARMUP=1000 scripts/profile.sh ${t}_walk_hfield --workload walk_hfield --min-seconds 0
 WARMUP=1000 scripts/profile.sh ${t}_walk_mesh --workload walk_mesh --min-seconds 0
 WARMUP=1000 scripts/profile.sh ${t}_walk_newton --workload walk_newton --min-seconds 0
+WARMUP=1000 scripts/profile.sh ${t}_walk_elliptic --workload walk_elliptic --min-seconds 0
+WARMUP=1000 scripts/profile.sh ${t}_walk_pairs_newton --workload walk_pairs_newton --min-seconds 0
 scripts/profile.sh ${t}_mixed --workload mixed --min-seconds 1
