@@ -147,17 +147,17 @@ def cpu_baseline(m, sim, target_seconds=12.0):
 
 
 def other_workloads(n_envs, chunk, device):
-    """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS) and configs[4] (eel + centipede buckets) on
+    """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS; and with the Newton solver) and configs[4] (eel + centipede buckets) on
     this GPU: env-steps/s over 500 timed steps after a warm-up (walking: 1000 steps, so that the animals stand and walk)."""
     import torch
     from farms_mujoco_amd.simulation.buckets import BucketedSimulation
     res = {}
-    for name, warm, steps in (('walk', 1000, 500), ('mixed', 300, 500)):
+    for name, warm, steps in (('walk', 1000, 500), ('walk_newton', 1000, 500), ('mixed', 300, 500)):
         if name == 'mixed':
             sims = [build_sim(n_envs//2, 1 << 30, chunk, 0, device, morphology='eel')[0],
                     build_sim(n_envs - n_envs//2, 1 << 30, chunk, n_envs//2, device, morphology='centipede')[0]]
         else:
-            sims = [build_sim(n_envs, 1 << 30, chunk, 0, device, workload='walk')[0]]
+            sims = [build_sim(n_envs, 1 << 30, chunk, 0, device, workload=name)[0]]
         batch = BucketedSimulation(sims)
         for _ in range(warm//chunk):
             batch.step_fused(chunk)
@@ -178,6 +178,7 @@ def other_workloads(n_envs, chunk, device):
         res[name] = {'value': n_envs*(steps//chunk)*chunk/dt, 'unit': 'env-steps/s', 'warmup': warm, 'steps': (steps//chunk)*chunk,
                      'launch_ms': {'min': float(ms.min()), 'median': float(np.median(ms)), 'max': float(ms.max())},
                      'config': 'BASELINE configs[3]: salamander-33 walking on a plane' if name == 'walk' else
+                               'configs[3] with MuJoCo\'s Newton solver (the reference\'s fallback, mjcf.py:1348-1359) instead of PGS x 50' if name == 'walk_newton' else
                                'BASELINE configs[4]: half eels, half centipedes, one bucket (launch, HIP stream) per morphology, side by side'}
         del sims, batch
     return res
