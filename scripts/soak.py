@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
-for workload, n in (('swim', 4096), ('walk', 4096), ('swim', 8191)):
+workloads = [(w, 4096) for w in os.environ['FMJ_SOAK'].split(',')] if 'FMJ_SOAK' in os.environ else (('swim', 4096), ('walk', 4096), ('swim', 8191))
+for workload, n in workloads:
     sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
     t0 = time.perf_counter()
     for _ in range((steps if workload == 'swim' else steps//4)//100):
