@@ -366,3 +366,35 @@ def test_primal_solvers_on_random_contact_trees(oracle, seed, solver, cone):
             assert np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max() < 2e-2*fs + 2e-3, (seed, e, con[e, :nc, 12:15], o['contact'][e, :nc, 12:15])
     ev = np.abs(d.qvel.cpu().numpy() - o['qvel']).max()/max(np.abs(o['qvel']).max(), 1e-9)
     assert ev < 3e-3, (seed, m.nbody, m.nv, ev)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'cg'])
+def test_elliptic_cone_more_rows_than_the_chip_holds(oracle, solver):
+    """Bellies pressed in (20 contacts = 60 cone rows) and six spine joints past their limits: more than 64 rows, so the rows, their
+    parameters and the values the rows of a contact exchange live in the HBM scratch of the env (the 'big' copy of the constraint
+    code) - same bounds as on chip."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _walker(solver=solver, cone='elliptic')
+    n = 6
+    rng = np.random.default_rng(5)
+    qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.05, 0.05, (n, m.nq - 7))
+    qpos[:, 2] = 0.012
+    qpos[:4, 7 + 2:7 + 8] = 1.25
+    qvel = rng.normal(size=(n, m.nv))*0.05; qvel[:, :2] += 0.2
+    phys = BatchedPhysics(m, n)
+    q32, v32, w32 = _set(phys, qpos, qvel, rng.normal(size=(n, m.nv))*2.0)
+    rows, _ = phys.step_debug(want_pgs=False)
+    torch.cuda.synchronize()
+    d = phys.data
+    assert int((d.status & ~8).abs().sum()) == 0                      # FMJ_WARN_CONTACTFULL allowed: both sides truncate alike
+    o = oracle.step_tf(m, q32, v32, ctrl=np.zeros((n, m.nu)), warmstart=w32, want_AR=False)
+    assert np.array_equal(d.ncon.cpu().numpy(), o['ncon']) and (o['nefc'][:4] > 64).all() and (o['nefc'][4:] <= 64).all()
+    rows = rows.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for e in range(n):
+        ne = int(o['nefc'][e]); fs = max(np.abs(o['efc'][e, :ne, 0]).max(), 1e-2)
+        worst = max(worst, np.abs(rows[e, :ne, 4] - o['efc'][e, :ne, 0]).max()/fs)
+    ev = np.abs(d.qvel.cpu().numpy() - o['qvel']).max()/np.abs(o['qvel']).max()
+    print(solver, 'elliptic, rows', o['nefc'], 'row forces', worst, 'qvel', ev)
+    assert worst < 3e-3 and ev < 3e-3
