@@ -1598,7 +1598,8 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
               *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
               *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
-              *(float4*)(ct + 12) = make_float4(dq[k], mu, __int_as_float(g), pp.z);
+              // geom | (last dof of its body's chain + 1) << 16: the Jacobian rows need the chain without a table read per contact
+              *(float4*)(ct + 12) = make_float4(dq[k], mu, __int_as_float(g | ((GTABI(g, 0).z + 1) << 16)), pp.z);
             }
           }
         }
@@ -1657,7 +1658,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
             *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
             *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
             *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
-            *(float4*)(ct + 12) = make_float4(dist, mu, __int_as_float(g2), __int_as_float(g1 | ((pr + 1) << 16)));
+            *(float4*)(ct + 12) = make_float4(dist, mu, __int_as_float(g2 | ((GTABI(g2, 0).z + 1) << 16)), __int_as_float(g1 | ((pr + 1) << 16)));
           }
         }
       }
@@ -2038,9 +2039,10 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     // pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 a contact force is a residual too small for an fp32 primal iteration (see
     // fmj_cons_rows.inc on the friction-0 pairs); ground contacts have no dual fallback in the Newton kernels, so say so here
     double gmu = 0;
+    const double isq = 1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0);      // the rule uses mu = friction / sqrt(impratio)
     for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] == FMJ_GEOM_PLANE || m->geom_type[g] == FMJ_GEOM_HFIELD) gmu = std::max(gmu, m->geom_friction[3 * g]);
     for (int g = 0; g < m->ngeom; g++)
-      if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) < 1e-3)
+      if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) * isq < 1e-3)
         return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: Newton / CG with the pyramidal cone need ground-contact friction >= 1e-3 in fp32 (R = 2 mu^2 R0 makes the rows too stiff below that): use solver = PGS, the elliptic cone, or give the geoms friction");
   }
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
