@@ -330,3 +330,22 @@ def test_two_collisions_with_one_name_sphere_then_mesh(tmp_path):
       </link></model></sdf>''')
     m = sdf2model(ModelSDF.read(str(tmp_path / 'm.sdf'))[0], plane=True, use_collisions=True)
     assert sorted(m.geom_type.tolist()) == [0, 2, 7] and m.nmeshvert == 4
+
+
+def test_solver_and_cone_options_reach_the_model_and_the_mjcf(sdf_path):
+    """simulation_options.solver / cone / impratio are forwarded like reference mjcf.py:1342-1353 does (round 3: Newton, CG and the
+    elliptic cone exist on the device); the exported MJCF names them."""
+    import xml.etree.ElementTree as ET
+    from farms_mujoco_amd.model import SOLVERS, CONES
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.mjcf import model2mjcf_xml
+    ao = _options(sdf_path)
+    so = SimulationOptions(solver='Newton', cone='elliptic', n_solver_iters=100, impratio=4.0)
+    m = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=so, use_collisions=True, plane=True)
+    assert m.solver == SOLVERS['newton'] and m.cone == CONES['elliptic'] and m.solver_iterations == 100 and m.impratio == 4.0
+    c = m.as_c()
+    assert c.solver == 2 and c.cone == 1
+    opt = ET.fromstring(model2mjcf_xml(m)).find('option')
+    assert opt.get('solver') == 'Newton' and opt.get('cone') == 'elliptic' and float(opt.get('impratio')) == 4.0
+    m = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=SimulationOptions(solver='CG'), use_collisions=True, plane=True)
+    assert m.solver == SOLVERS['cg'] and m.cone == CONES['pyramidal']
