@@ -244,6 +244,46 @@ def test_from_sdf_end_to_end(oracle, tmp_path):
     assert _relerr(sim.task.data.sensors.xfrc.array.cpu().numpy(), ref['xfrc']) < 1e-3
 
 
+@pytest.mark.parametrize('solver,cone', [('Newton', 'pyramidal'), ('Newton', 'elliptic'), ('CG', 'pyramidal')])
+def test_from_sdf_on_the_ground_with_the_primal_solvers(oracle, tmp_path, solver, cone):
+    """The host API end to end with the options the reference forwards to MuJoCo (mjcf.py:1342-1353): Simulation.from_sdf compiles the
+    SDF with simulation_options.solver / cone, drops the animal on a flat arena and runs 200 fused iterations; state and link rows
+    against the oracle stepping the same compiled model."""
+    import torch
+    from test_sdf_compiler import SDF, _options
+    from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, WaterOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    from farms_mujoco_amd.simulation.mjcf import setup_model
+    from farms_mujoco_amd.model import SOLVERS, CONES
+    p = tmp_path/'swimmer.sdf'; p.write_text(SDF)
+    ao = _options(str(p))
+    ao.spawn.pose = [0.0, 0.0, 0.08, 0.0, 0.0, 0.0]
+    for lo in ao.morphology.links:                       # the arena has friction 0 (mjcf.py:1202): a contact's friction is its link's (:1420-1422)
+        lo.friction = [0.7, 0.0, 0.0]
+    n, T = 6, 200
+    psi = np.linspace(0, 5, n)
+    opts = SimulationOptions(timestep=1e-3, n_iterations=T, solver=solver, cone=cone, n_solver_iters=100)
+    arena = ArenaOptions(water=WaterOptions(height=None, drag=False), ground_height=0.0)
+    m = setup_model(opts, ao, arena)
+    assert m.solver == SOLVERS[solver.lower()] and m.cone == CONES[cone]
+    sim = Simulation.from_sdf(opts, ao, arena, n_envs=n, buffer_size=T, controller=_SdfWave(m, psi))
+    sim.reset()
+    m = sim.physics.model
+    st = _oracle_initial_state(oracle, sim, m)
+    c = sim.task._controller
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    ref = oracle.run_fused(m, st, T, buffer_size=T, controller=1,
+                           wave=dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
+                                     env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency))
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0 and int(d.ncon.max()) >= 1            # it lies on the floor
+    e = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print(solver, cone, 'from_sdf on the ground: qpos abs err per env', e)
+    assert e.max() < 5e-5                                       # measured 2e-7 .. 1.3e-6
+    assert _relerr(sim.task.data.sensors.links.array.cpu().numpy(), ref['links']) < 1e-3
+
+
 def _SdfWave(m, psi):
     """Wave controller on every position actuator of an arbitrary model (joint names are not 'joint_body_*')."""
     import torch
