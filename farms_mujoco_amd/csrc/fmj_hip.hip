@@ -1470,7 +1470,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
               const q4 bqq = {bq.x, bq.y, bq.z, bq.w};
               const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
-              rad = gs.x; mu = fmaxf(pp.x, gs.w);
+              rad = gs.x; mu = fmaxf(fmaxf(pp.x, gs.w), 1e-5f);
               v3 ax = mk3(0.f, 0.f, 0.f);
               if (gi.x == FMJ_GEOM_CAPSULE) { const q4 gqq = {gq.x, gq.y, gq.z, gq.w}; ax = scl3(qrot(qmul(bqq, gqq), mk3(0.f, 0.f, 1.f)), gs.y); }
               const v3 c0 = add3(cen, ax), c1 = sub3(cen, ax);
@@ -1491,7 +1491,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               const q4 wq = qmul(bqq, gqq);
               const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
               const v3 ex = scl3(qrot(wq, mk3(1.f, 0.f, 0.f)), gs.x), ey = scl3(qrot(wq, mk3(0.f, 1.f, 0.f)), gs.y), ez = scl3(qrot(wq, mk3(0.f, 0.f, 1.f)), gs.z);
-              mu = fmaxf(pp.x, gs.w);
+              mu = fmaxf(fmaxf(pp.x, gs.w), 1e-5f);
 #pragma unroll
               for (int corner = 0; corner < 8; corner++) {
                 const v3 c = add3(add3(cen, (corner & 1) ? ex : scl3(ex, -1.f)), add3((corner & 2) ? ey : scl3(ey, -1.f), (corner & 4) ? ez : scl3(ez, -1.f)));
@@ -1519,7 +1519,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               if (len2 >= 1e-30f) vec = scl3(vec, gs.x / sqrtf(len2)); else vec = scl3(qrot(wq, mk3(1.f, 0.f, 0.f)), gs.x);
               const float prjvec = dot3(vec, nrm_);
               axis = scl3(axis, gs.y); prjaxis *= gs.y;
-              mu = fmaxf(pp.x, gs.w);
+              mu = fmaxf(fmaxf(pp.x, gs.w), 1e-5f);
               const float d0 = dist + prjaxis + prjvec;
               if (d0 < 0.f) {
                 cq[0] = add3(cen, add3(vec, axis)); dq[0] = d0; cnt = 1;
@@ -1551,7 +1551,7 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
               const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
               const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
               const v3 cen = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
-              mu = fmaxf(pp.x, gs.w);
+              mu = fmaxf(fmaxf(pp.x, gs.w), 1e-5f);
               v3 nc0;
               if (ground_dist(M, pl, pn, pp, cen, &nc0) < gs.z) {       // the ground is within the bounding radius
                 const m33 R = q2m(qmul(bqq, gqq));
@@ -2035,15 +2035,17 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path covers limits and ground contacts: no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG (the PGS kernel implements the pyramidal cone only)");
+  // Pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 (the reference's arena has friction 0, mjcf.py:1202, so a contact's friction is
+  // its link's - 1e-5 after MuJoCo's clamp when the link has none) a contact force is a residual too small for an fp32 primal
+  // iteration (see fmj_cons_rows.inc on the friction-0 pairs).  Such a model is solved on the dual problem throughout: the PGS
+  // kernels, run to the solver's tolerance (up to 10 x solver_iterations sweeps) - the same convex problem, the same minimiser.
+  bool dual_instead = false;
   if (cons && m->solver != FMJ_SOLVER_PGS && m->cone == FMJ_CONE_PYRAMIDAL && nplane > 0) {
-    // pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 a contact force is a residual too small for an fp32 primal iteration (see
-    // fmj_cons_rows.inc on the friction-0 pairs); ground contacts have no dual fallback in the Newton kernels, so say so here
     double gmu = 0;
     const double isq = 1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0);      // the rule uses mu = friction / sqrt(impratio)
     for (int g = 0; g < m->ngeom; g++) if (m->geom_type[g] == FMJ_GEOM_PLANE || m->geom_type[g] == FMJ_GEOM_HFIELD) gmu = std::max(gmu, m->geom_friction[3 * g]);
     for (int g = 0; g < m->ngeom; g++)
-      if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) * isq < 1e-3)
-        return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: Newton / CG with the pyramidal cone need ground-contact friction >= 1e-3 in fp32 (R = 2 mu^2 R0 makes the rows too stiff below that): use solver = PGS, the elliptic cone, or give the geoms friction");
+      if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) * isq < 1e-3) dual_instead = true;
   }
   if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
@@ -2224,9 +2226,9 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     // the HBM constraint path keeps A in rows of AG_LD floats and three 64-row slots per lane (fmj_cons_rows.inc)
     if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
   }
-  D.solver_iterations = m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
+  D.solver_iterations = dual_instead ? 10 * m->solver_iterations : m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.cone = cons ? m->cone : FMJ_CONE_PYRAMIDAL;
-  D.solver = cons ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
+  D.solver = (cons && !dual_instead) ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
   D.ls_tolerance = (float)(m->ls_tolerance > 0 ? m->ls_tolerance : 0.01);
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
   D.pgs_scale = (float)(1.0 / ((m->meaninertia > 0 ? m->meaninertia : 1.0) * (nv > 1 ? nv : 1)));

@@ -553,7 +553,7 @@ static void collide_plane(const fmj_model* m, ws_t* w, int p, int g, int* warn) 
   rot_vec_quat(v, m->geom_pos + 3 * g, w->xquat + 4 * gb);
   for (int k = 0; k < 3; k++) gpos[k] = w->xpos[3 * gb + k] + v[k];
   quat2mat(gm, gq);
-  double mu = fmax(m->geom_friction[3 * p], m->geom_friction[3 * g]);
+  double mu = fmax(fmax(m->geom_friction[3 * p], m->geom_friction[3 * g]), 1e-5);      /* max over the two geoms (mj_contactParam), floor mjMINMU */
   const double* size = m->geom_size + 3 * g;
   int type = m->geom_type[g];
   if (type == FMJ_GEOM_SPHERE || type == FMJ_GEOM_CAPSULE) {

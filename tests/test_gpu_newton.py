@@ -444,3 +444,48 @@ def test_primal_solvers_on_random_mesh_trees(oracle, seed, solver, cone):
     for e in range(n):
         ev = np.abs(d.qvel.cpu().numpy()[e] - o['qvel'][e]).max()/vs
         assert ev < (3e-3 if o['nefc'][e] <= 64 else 1e-2), (seed, e, int(o['nefc'][e]), ev)
+
+
+@pytest.mark.parametrize('solver', ['newton', 'cg'])
+def test_frictionless_contacts_under_the_primal_solvers(oracle, solver):
+    """The reference's arena has friction 0 (mjcf.py:1202) and a link without a friction option brings none either: the contact's
+    friction is MuJoCo's floor 1e-5 and its pyramid rows carry R = 2 mu^2 R0 ~ 1e-10 R0, out of reach of an fp32 primal iteration.
+    fmj_create then solves the whole model on the dual problem (PGS to the solver's tolerance, up to 10 x solver_iterations sweeps).
+    A salamander settling on a frictionless floor, bellies pressed in and a joint past its limit.  The reference solution is the
+    oracle's PGS with the same sweep budget: on the stiffest of these states (14 belly contacts, D = 1e10) the oracle's own fp64
+    Newton does not get through in 100 iterations (it ends at a dual cost of +2e12), where it does the dual solve is within
+    1e-3 of it."""
+    import torch
+    from farms_mujoco_amd.model import salamander33, SOLVERS
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = salamander33(contacts=True, limits=True, spawn_z=0.045)
+    m.geom_friction = np.zeros_like(m.geom_friction)
+    m.solver = SOLVERS[solver]; m.solver_iterations = 100
+    mo = copy.copy(m); mo.solver = SOLVERS['pgs']; mo.solver_iterations = 1000
+    n = 8
+    rng = np.random.default_rng(2)
+    qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.1, 0.1, (n, m.nq - 7))
+    qpos[:3, 2] = 0.015; qpos[:, 7 + 3] = 1.25
+    qvel = rng.normal(size=(n, m.nv))*0.05; qvel[:, :2] += 0.2
+    phys = BatchedPhysics(m, n)
+    q32, v32, w32 = _set(phys, qpos, qvel)
+    phys.step(1)
+    torch.cuda.synchronize()
+    d = phys.data
+    o = oracle.step_tf(mo, q32, v32, ctrl=np.zeros((n, m.nu)), warmstart=w32, want_AR=False)
+    assert int(d.status.abs().sum()) == 0 and np.array_equal(d.ncon.cpu().numpy(), o['ncon']) and o['ncon'].min() >= 1
+    con = oracle.contacts_from_hip(d.contact.cpu().numpy())
+    worst = 0.0
+    for e in range(n):
+        nc = int(o['ncon'][e]); fs = max(np.abs(o['contact'][e, :nc, 12]).max(), 1e-2)
+        worst = max(worst, np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max()/fs)
+    ev = np.abs(d.qvel.cpu().numpy() - o['qvel']).max()/np.abs(o['qvel']).max()
+    print(solver, 'frictionless: contact-frame forces', worst, 'qvel', ev)
+    assert worst < 3e-3 and ev < 3e-3
+    phys.step(59)
+    torch.cuda.synchronize()
+    ref = oracle.step(mo, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=60, n_threads=8)
+    assert int(d.status.abs().sum()) == 0 and int(ref['status'].sum()) == 0
+    e60 = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    print('  qpos abs err after 60 steps', e60)
+    assert np.median(e60) < 2e-4 and e60.max() < 2e-3

@@ -150,8 +150,8 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     assert rc == 2 and 'no explicit pairs' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True)
     m.solver = SOLVERS['newton']; m.geom_friction = m.geom_friction*0.0
-    rc, msg = create(m)
-    assert rc == 2 and 'friction >= 1e-3' in msg, (rc, msg)
+    rc, msg = create(m)                                      # frictionless contacts under Newton: accepted (solved on the dual problem)
+    assert rc in (0, 4), (rc, msg)                           # 4 = FMJ_ERR_NODEVICE on a box without a GPU: the model itself passed
     m = salamander33(contacts=True, limits=True)
     m.cone = 1
     rc, msg = create(m)

@@ -42,7 +42,7 @@ def test_friction_holds_below_cone_and_slides_above(oracle):
         if ax_expected == 'roll':
             assert abs(vx - wy*0.05) < 2e-3*abs(vx) + 1e-4 and wy > 0.1      # v = w r : no slip at the contact
         else:
-            assert abs(wy) < 1e-9 and vx > 0.3                              # frictionless: pure sliding, no spin
+            assert abs(wy) < 1e-5 and vx > 0.3                              # frictionless (MuJoCo floors friction at mjMINMU = 1e-5): sliding, spin 2e-6
 
 
 def test_capsule_two_contacts(oracle):
