@@ -129,7 +129,7 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
         flags = ['--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC'] + list(defines)
         with tempfile.TemporaryDirectory(prefix='fmj_build_') as tmp:
             jobs = [(os.path.join(tmp, 'host.o'), [])] + [(os.path.join(tmp, f'k{n}.o'), [f'-DFMJ_TU_MAXD={n}'])
-                                                          for n in range(4, 33, 4)]
+                                                          for n in range(4, 65, 4)]      # 36 .. 64: the unconstrained one-env kernel only
 
             def cc(job):
                 obj, defs = job

@@ -35,7 +35,8 @@
 #include "../../include/fmj.h"
 
 #define FMJ_MAX_LANES 64
-#define FMJ_MAXD 32         // max dof-chain length (register row length)
+#define FMJ_MAXD 32         // max dof-chain length (register row length) of models with limits / contacts and of the two-env kernel
+#define FMJ_MAXD_DEEP 64    // ... of the one-env kernel without constraints (long swimmers: an eel of 58 joints)
 #define FMJ_MAXBD 32        // max body-chain length
 
 static thread_local std::string g_err;
@@ -609,6 +610,14 @@ __device__ __forceinline__ void ldl_factor(float* HR, float* DV, const WideRound
       ROUND_BODY(NG_); \
       p0 = np0; p1 = np1; p2 = np2; p3 = np3; p4 = np4; p5 = np5; a0 = na0; a1 = na1; a2 = na2; a3 = na3; a4 = na4; a5 = na5; dep = ndep; np = nnp; rd++; \
     }
+    if (MAXD >= 64) ROUNDS_AT((MAXD >= 64 ? 16 : 1), dep > 60)
+    if (MAXD >= 60) ROUNDS_AT((MAXD >= 60 ? 15 : 1), dep > 56)
+    if (MAXD >= 56) ROUNDS_AT((MAXD >= 56 ? 14 : 1), dep > 52)
+    if (MAXD >= 52) ROUNDS_AT((MAXD >= 52 ? 13 : 1), dep > 48)
+    if (MAXD >= 48) ROUNDS_AT((MAXD >= 48 ? 12 : 1), dep > 44)
+    if (MAXD >= 44) ROUNDS_AT((MAXD >= 44 ? 11 : 1), dep > 40)
+    if (MAXD >= 40) ROUNDS_AT((MAXD >= 40 ? 10 : 1), dep > 36)
+    if (MAXD >= 36) ROUNDS_AT((MAXD >= 36 ? 9 : 1), dep > 32)
     if (MAXD >= 32) ROUNDS_AT((MAXD >= 32 ? 8 : 1), dep > 28)
     if (MAXD >= 28) ROUNDS_AT((MAXD >= 28 ? 7 : 1), dep > 24)
     if (MAXD >= 24) ROUNDS_AT((MAXD >= 24 ? 6 : 1), dep > 20)
@@ -944,7 +953,7 @@ __device__ __forceinline__ void emit_links_and_drag(MT& M, AT& A, int env, int i
 // MESH: the narrow phase has the convex-mesh vertex loop (~20 VGPRs); on by itself for models with mesh geoms but no explicit pairs,
 // which then do not pay for the fork code of PAIRS (its spills cost the mesh-foot walker 52 KB of scratch traffic per env-step).
 template <bool FUSED, int MAXD, bool CONS, bool PAIRS = false, bool NEWTON = false, bool MESH = PAIRS, bool ELL = false>
-__global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
+__global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kernel(const DevModel M_by_value, const StepArgs A_by_value) {
   extern __shared__ __align__(16) float lds[];
   // the two arguments are read where they are used, through the kernarg segment (scalar loads), instead of being held
   // in SGPRs - and spilled - for the whole launch (see fmj_dual2.inc); the pointers are laundered once per step
@@ -1779,6 +1788,10 @@ __global__ void __launch_bounds__(64, CONS ? 2 : 4) fmj_step_kernel(const DevMod
 #define FMJ_CAT2(a, b) a##b
 #define FMJ_CAT(a, b) FMJ_CAT2(a, b)
 extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, FMJ_TU_MAXD)(int fused, int cons, int dual) {
+#if FMJ_TU_MAXD > 32        // rows longer than 32: the unconstrained one-env kernel only (FMJ_MAXD_DEEP)
+  (void)cons; (void)dual;
+  return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
+#else
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
@@ -1790,6 +1803,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (cons == 2) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true>;
   if (cons) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
+#endif
 }
 #else
 
@@ -1922,6 +1936,8 @@ typedef void (*step_kernel_t)(const DevModel, const StepArgs);
 extern "C" {
 void* fmj_tu_kernel_4(int, int, int);  void* fmj_tu_kernel_8(int, int, int);  void* fmj_tu_kernel_12(int, int, int); void* fmj_tu_kernel_16(int, int, int);
 void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); void* fmj_tu_kernel_28(int, int, int); void* fmj_tu_kernel_32(int, int, int);
+void* fmj_tu_kernel_36(int, int, int); void* fmj_tu_kernel_40(int, int, int); void* fmj_tu_kernel_44(int, int, int); void* fmj_tu_kernel_48(int, int, int);
+void* fmj_tu_kernel_52(int, int, int); void* fmj_tu_kernel_56(int, int, int); void* fmj_tu_kernel_60(int, int, int); void* fmj_tu_kernel_64(int, int, int);
 }
 static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes), 7 Newton / CG + explicit pairs (+ meshes)
   void* k;
@@ -1933,7 +1949,15 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
     case 20: k = fmj_tu_kernel_20(fused, cons, dual); break;
     case 24: k = fmj_tu_kernel_24(fused, cons, dual); break;
     case 28: k = fmj_tu_kernel_28(fused, cons, dual); break;
-    default: k = fmj_tu_kernel_32(fused, cons, dual); break;
+    case 32: k = fmj_tu_kernel_32(fused, cons, dual); break;
+    case 36: k = fmj_tu_kernel_36(fused, cons, dual); break;
+    case 40: k = fmj_tu_kernel_40(fused, cons, dual); break;
+    case 44: k = fmj_tu_kernel_44(fused, cons, dual); break;
+    case 48: k = fmj_tu_kernel_48(fused, cons, dual); break;
+    case 52: k = fmj_tu_kernel_52(fused, cons, dual); break;
+    case 56: k = fmj_tu_kernel_56(fused, cons, dual); break;
+    case 60: k = fmj_tu_kernel_60(fused, cons, dual); break;
+    default: k = fmj_tu_kernel_64(fused, cons, dual); break;
   }
   return (step_kernel_t)k;
 }
@@ -2088,7 +2112,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (ddepth[d] > max_ddepth) max_ddepth = ddepth[d];
   }
   for (int d = nv - 1; d >= 0; d--) if (m->dof_parentid[d] >= 0) dsub[m->dof_parentid[d]] += dsub[d];
-  if (max_ddepth + 1 > FMJ_MAXD) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: dof chain longer than 32");
+  if (max_ddepth + 1 > (cons ? FMJ_MAXD : FMJ_MAXD_DEEP))
+    return set_err(FMJ_ERR_UNSUPPORTED, cons ? "fmj_create: dof chain longer than 32 in a model with limits / contacts (64 without)" : "fmj_create: dof chain longer than 64");
   std::vector<int> nact(nj, 0);
   for (int a = 0; a < nu; a++) {
     int j = m->actuator_jntid[a];

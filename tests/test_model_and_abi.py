@@ -138,7 +138,13 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
         return rc, lib.fmj_last_error().decode()
     rc, msg = create(eel(n_joints=70))                       # 71 bodies, nv 76
     assert rc == 2 and '64' in msg and 'wavefront' in msg, (rc, msg)
-    rc, msg = create(eel(n_joints=40))                       # nv 46 fits a wave, its dof chain of 46 does not fit the register row
+    rc, msg = create(eel(n_joints=40))                       # nv 46, dof chain of 46: accepted without constraints (rows of up to 64, round 3)
+    assert rc in (0, 4), (rc, msg)
+    e40 = eel(n_joints=40)                                   # ... but not with limits / contacts (row of 32 there)
+    for k in ('jnt_limited',):
+        setattr(e40, k, np.ones_like(getattr(e40, k)))
+    e40.jnt_range = np.tile([-1.0, 1.0], (e40.njnt, 1)).astype(float)
+    rc, msg = create(e40)
     assert rc == 2 and 'chain longer than 32' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True)
     m.solver = 7
