@@ -66,7 +66,7 @@ def _bucket_sim(maker, n, T, ring, env_offset=0, seed=9, twins=()):
     from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
     from farms_mujoco_amd.control import WaveController
     from farms_mujoco_amd.simulation.simulation import Simulation
-    m = getattr(mm, maker)()
+    m = mm.eel(n_joints=int(maker[3:])) if maker.startswith('eel') and len(maker) > 3 else getattr(mm, maker)()
     qpos, qvel, psi = mm.synthetic_batch(m, n, seed=seed, env_offset=env_offset)
     for e in twins:
         qpos[e] = qpos[0]; qvel[e] = qvel[0]; psi[e] = psi[0]
@@ -96,6 +96,29 @@ def _bucket_oracle(oracle, sim, m, T, ring, envs):
     wave = dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(), env_phase=c.env_phase[envs].cpu().numpy(),
                 frequency=c.frequency)
     return oracle.run_fused(m, st, T, swim=h.swim_dict(), water=water, buffer_size=ring, controller=1, wave=wave, n_threads=8)
+
+
+def test_fused_swim_of_a_long_eel(oracle):
+    """The fused loop (rows, drag, wave controller) of an eel of 48 joints - a dof chain of 54: the MAXD 56 build of the
+    unconstrained one-env kernel - against the oracle's fused loop, bounds against the fp32-storage floor like the mixed batch."""
+    import torch
+    T = 40
+    sim, m = _bucket_sim('eel48', 12, T, T)
+    assert m.nv == 54
+    ref = _bucket_oracle(oracle, sim, m, T, T, list(range(12)))
+    with oracle.fp32_storage():
+        flo = _bucket_oracle(oracle, sim, m, T, T, list(range(12)))
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    assert int(sim.physics.data.status.abs().sum()) == 0
+    sens = sim.task.data.sensors
+    got = dict(qpos=sim.physics.data.qpos.cpu().numpy(), links=sens.links.array.cpu().numpy(), xfrc=sens.xfrc.array.cpu().numpy())
+    groups = dict(qpos=qpos_groups(m), links=link_row_groups(), xfrc=[slice(0, 3), slice(3, 6)])
+    for k in got:
+        err = group_relerr(got[k], ref[k], groups[k]); fl = group_relerr(flo[k], ref[k], groups[k])
+        print('eel48', k, 'err', err, 'fp32-storage floor', fl)
+        assert err < 6*fl + 1e-6, (k, err, fl)
+    assert np.abs(sens.links.array.cpu().numpy()[-1, :, :, 14:17]).max() > 1e-3      # it swims
 
 
 def test_mixed_batch_bucketed(oracle):
