@@ -24,6 +24,14 @@ class SimulationOptions:
         self.solver = kwargs.pop('solver', 'PGS')
         self.n_solver_iters = kwargs.pop('n_solver_iters', 50)
         self.impratio = kwargs.pop('impratio', 1)
+        # forwarded to the option block by the reference (mjcf.py:1366-1403); ccd / mpr settings drive MuJoCo's general convex
+        # collider, which this path does not use (its narrow phase is analytic), so they are accepted and ignored
+        self.noslip_iterations = kwargs.pop('noslip_iterations', 0)
+        self.noslip_tolerance = kwargs.pop('noslip_tolerance', 1e-6)
+        self.ccd_iterations = kwargs.pop('ccd_iterations', 1000)
+        self.ccd_tolerance = kwargs.pop('ccd_tolerance', 1e-6)
+        self.mpr_iterations = kwargs.pop('mpr_iterations', 1000)
+        self.mpr_tolerance = kwargs.pop('mpr_tolerance', 1e-6)
         assert not kwargs, kwargs
 
     def save(self, path):

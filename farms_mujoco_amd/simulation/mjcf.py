@@ -92,6 +92,8 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
         b.options['impratio'] = float(simulation_options.impratio)
         b.options['solver'] = str(getattr(simulation_options, 'solver', 'PGS'))       # mjcf.py:1348-1353
         b.options['cone'] = str(getattr(simulation_options, 'cone', 'pyramidal'))     # mjcf.py:1342-1347
+        b.options['noslip_iterations'] = int(getattr(simulation_options, 'noslip_iterations', 0))        # mjcf.py:1392-1397
+        b.options['noslip_tolerance'] = float(getattr(simulation_options, 'noslip_tolerance', 1e-6))    # mjcf.py:1398-1403
 
     link_opts = {l.name: l for l in animat_options.morphology.links} if animat_options is not None else {}
     joint_opts = {j.name: j for j in animat_options.morphology.joints} if animat_options is not None else {}
@@ -309,7 +311,8 @@ def model2mjcf_xml(m: Model) -> str:
                   boundmass='0', boundinertia='0', fusestatic='true')
     ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone={0: 'pyramidal', 1: 'elliptic'}[int(getattr(m, 'cone', 0))],
                   solver={0: 'PGS', 1: 'CG', 2: 'Newton'}[int(getattr(m, 'solver', 0))], iterations=str(int(m.solver_iterations)), tolerance=repr(float(m.solver_tolerance)),
-                  impratio=repr(float(m.impratio)))
+                  impratio=repr(float(m.impratio)), noslip_iterations=str(int(getattr(m, 'noslip_iterations', 0))),
+                  noslip_tolerance=repr(float(getattr(m, 'noslip_tolerance', 1e-6))))
     ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))
     world = ET.SubElement(root, 'worldbody')
     elems = {0: world}

@@ -400,7 +400,7 @@ def test_elliptic_cone_more_rows_than_the_chip_holds(oracle, solver):
     assert worst < 3e-3 and ev < 3e-3
 
 
-@pytest.mark.parametrize('seed', range(300, 306))
+@pytest.mark.parametrize('seed', (301, 302, 303, 304, 305, 306))      # = test_gpu_random_trees.MESH_SEEDS[:6]: every draw has mesh geoms
 @pytest.mark.parametrize('solver,cone', [('newton', 'pyramidal'), ('newton', 'elliptic')])
 def test_primal_solvers_on_random_mesh_trees(oracle, seed, solver, cone):
     """Random trees whose collision shapes include convex meshes (hulls of 4 to ~30 vertices), with limits, over a plane, under Newton
@@ -410,8 +410,7 @@ def test_primal_solvers_on_random_mesh_trees(oracle, seed, solver, cone):
     from farms_mujoco_amd.physics import BatchedPhysics
     from test_gpu_random_trees import random_tree, FMJ_WARN_CONTACTFULL
     m = random_tree(seed, contacts=True, meshes=True)
-    if m is None or m.nv == 0 or m.nmeshvert == 0:
-        pytest.skip('degenerate draw')
+    assert m is not None and m.nv > 0 and m.nmeshvert > 0, f'seed {seed} no longer draws a tree with mesh geoms'
     m.solver = SOLVERS[solver]; m.cone = CONES[cone]; m.solver_iterations = 100
     rng = np.random.default_rng(5000 + seed)
     n = 6

@@ -349,3 +349,21 @@ def test_solver_and_cone_options_reach_the_model_and_the_mjcf(sdf_path):
     assert opt.get('solver') == 'Newton' and opt.get('cone') == 'elliptic' and float(opt.get('impratio')) == 4.0
     m = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=SimulationOptions(solver='CG'), use_collisions=True, plane=True)
     assert m.solver == SOLVERS['cg'] and m.cone == CONES['pyramidal']
+
+
+def test_noslip_options_reach_the_model_and_the_mjcf(sdf_path):
+    """simulation_options.noslip_iterations / noslip_tolerance are forwarded like reference mjcf.py:1392-1403 does, so that a run
+    configured with the noslip post-pass reaches fmj_create's handling of it instead of silently stepping without it."""
+    import xml.etree.ElementTree as ET
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.mjcf import model2mjcf_xml
+    ao = _options(sdf_path)
+    so = SimulationOptions(noslip_iterations=7, noslip_tolerance=1e-5)
+    m = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=so, use_collisions=True, plane=True)
+    assert m.noslip_iterations == 7 and m.noslip_tolerance == 1e-5
+    c = m.as_c()
+    assert c.noslip_iterations == 7 and c.noslip_tolerance == 1e-5
+    opt = ET.fromstring(model2mjcf_xml(m)).find('option')
+    assert int(opt.get('noslip_iterations')) == 7 and float(opt.get('noslip_tolerance')) == 1e-5
+    m0 = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=SimulationOptions(), use_collisions=True, plane=True)
+    assert m0.noslip_iterations == 0
