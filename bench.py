@@ -141,9 +141,35 @@ def cpu_baseline(m, sim, target_seconds=12.0):
     oracle.run_fused(m, st, n_steps, swim=h.swim_dict(), water=water, buffer_size=100, controller=1, wave=wave,
                      n_threads=cores)                                          # rows go to a 100-row ring, like the GPU run
     dt = time.perf_counter() - t0
-    return dict(value=n_envs*n_steps/dt, unit='env-steps/s', cores=cores, kind='port',
-                sample=f'{n_envs} envs x {n_steps} steps of the same salamander-33 swim workload, fp64 C oracle '
-                       f'(not MuJoCo), {cores} pthreads, {dt:.2f} s')
+    out = dict(value=n_envs*n_steps/dt, unit='env-steps/s', cores=cores, kind='port',
+               sample=f'{n_envs} envs x {n_steps} steps of the same salamander-33 swim workload, fp64 C oracle '
+                      f'(not MuJoCo), {cores} pthreads, {dt:.2f} s')
+    out['mj_step'] = mujoco_baseline(m, qpos, qvel)
+    return out
+
+
+def mujoco_baseline(m, qpos, qvel, target_seconds=5.0):
+    """if ``mujoco`` imports on this box, the reference's own inner call - a bare ``mujoco.mj_step`` loop on the
+    exported MJCF of the same model (reference simulation.py:83-89,156), one env, one thread, no drag / readout - is timed as well
+    and labelled separately.  It does not import here or on the GPU box of this pipeline: the field then says so."""
+    try:
+        import mujoco
+    except ImportError:
+        return {'value': None, 'unit': 'env-steps/s', 'note': 'mujoco is not importable on this box: the reference\'s mj_step loop cannot be timed (BASELINE.md 2)'}
+    from farms_mujoco_amd.simulation.mjcf import model2mjcf_xml
+    mj = mujoco.MjModel.from_xml_string(model2mjcf_xml(m, fusestatic=False))
+    d = mujoco.MjData(mj)
+    d.qpos[:] = qpos[0]; d.qvel[:] = qvel[0]
+    for _ in range(200):
+        mujoco.mj_step(mj, d)
+    n, t0 = 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_seconds:
+        for _ in range(1000):
+            mujoco.mj_step(mj, d)
+        n += 1000
+    dt = time.perf_counter() - t0
+    return {'value': n/dt, 'unit': 'env-steps/s', 'cores': 1, 'kind': 'reference',
+            'note': f'bare mujoco.mj_step loop (mujoco {mujoco.__version__}), 1 env, 1 thread, {n} steps in {dt:.2f} s; no drag callback, no readout'}
 
 
 def other_workloads(n_envs, chunk, device):

@@ -296,27 +296,33 @@ def setup_model(simulation_options, animat_options, arena_options=None, **kwargs
                         if k in ('solref', 'solimp', 'friction') or k.startswith(('act_pos_', 'act_vel_'))}, **kwargs)
 
 
-def model2mjcf_xml(m: Model) -> str:
+def model2mjcf_xml(m: Model, fusestatic: bool = True) -> str:
     """The compiled model as an MJCF document (what ``Simulation.save_mjcf_xml`` writes in the reference,
-    simulation.py:215-225 via ``mjcf.export_with_assets``): compiler / option blocks as mjcf.py:1244-1403 sets them,
-    the body tree with explicit inertials, joints, collision geoms, the actuator triple and the sensors of
-    mjcf.py:950-1002.  The text loads in MuJoCo; nothing in this package reads it back."""
+    simulation.py:215-225 via ``mjcf.export_with_assets``): compiler / option / size blocks as mjcf.py:1244-1403 sets them,
+    the body tree with explicit inertials, joints, collision geoms (animat geoms collide with the arena only:
+    mjcf.py:251-267,1415-1424), the heightfield asset with its elevation data (task.py:108-115), convex meshes, the explicit
+    self-collision pairs (mjcf.py:1012-1033), the actuator triple and the sensors of mjcf.py:950-1002, keyframe 0.
+    The text loads in MuJoCo (tests/test_vs_mujoco.py steps it next to the oracle when ``mujoco`` is importable); nothing in
+    this package reads it back.  ``fusestatic=False`` keeps jointless bodies as bodies of their own, so that MuJoCo's body
+    ids are this model's (the reference compiles with fusestatic=True, mjcf.py:1252: same physics, fewer bodies)."""
     import xml.etree.ElementTree as ET
-    from ..model import JNT_FREE, JNT_SLIDE, GEOM_PLANE, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX
+    from ..model import JNT_FREE, JNT_SLIDE, GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH
 
     def v(a):
         return ' '.join(repr(float(x)) for x in np.asarray(a).ravel())
     root = ET.Element('mujoco', model=str(getattr(m, 'name', 'animat')))
     ET.SubElement(root, 'compiler', angle='radian', eulerseq='xyz', inertiafromgeom='false', balanceinertia='false',
-                  boundmass='0', boundinertia='0', fusestatic='true')
+                  boundmass='0', boundinertia='0', fusestatic='true' if fusestatic else 'false')
     ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone={0: 'pyramidal', 1: 'elliptic'}[int(getattr(m, 'cone', 0))],
                   solver={0: 'PGS', 1: 'CG', 2: 'Newton'}[int(getattr(m, 'solver', 0))], iterations=str(int(m.solver_iterations)), tolerance=repr(float(m.solver_tolerance)),
+                  ls_iterations=str(int(getattr(m, 'ls_iterations', 50))), ls_tolerance=repr(float(getattr(m, 'ls_tolerance', 0.01))),
                   impratio=repr(float(m.impratio)), noslip_iterations=str(int(getattr(m, 'noslip_iterations', 0))),
                   noslip_tolerance=repr(float(getattr(m, 'noslip_tolerance', 1e-6))))
-    ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)))
+    ET.SubElement(root, 'size', nconmax=str(max(int(m.max_contacts), 1)), nkey='1')
+    asset = ET.SubElement(root, 'asset')
     world = ET.SubElement(root, 'worldbody')
     elems = {0: world}
-    gtypes = {GEOM_PLANE: 'plane', 1: 'hfield', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_CYLINDER: 'cylinder', GEOM_BOX: 'box'}
+    gtypes = {GEOM_PLANE: 'plane', GEOM_HFIELD: 'hfield', GEOM_SPHERE: 'sphere', GEOM_CAPSULE: 'capsule', GEOM_CYLINDER: 'cylinder', GEOM_BOX: 'box'}
     for b in range(1, m.nbody):
         e = ET.SubElement(elems[int(m.body_parentid[b])], 'body', name=m.body_names[b], pos=v(m.body_pos[b]), quat=v(m.body_quat[b]))
         elems[b] = e
@@ -336,20 +342,43 @@ def model2mjcf_xml(m: Model) -> str:
                     at.update(limited='true', range=v(m.jnt_range[j]), margin=repr(float(m.jnt_margin[j])),
                               solreflimit=v(m.jnt_solref[j]), solimplimit=v(m.jnt_solimp[j]))
                 ET.SubElement(e, 'joint', **at)
-    asset = None
     for g in range(m.ngeom):
         t = int(m.geom_type[g])
-        common = dict(pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]), friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]),
-                      solimp=v(m.geom_solimp[g]), condim='3', margin='0')
-        if t == 7:                                   # convex mesh: its hull vertices as an inline mesh asset
-            if asset is None:
-                asset = ET.Element('asset'); root.insert(list(root).index(world), asset)
+        ground = int(m.geom_bodyid[g]) == 0
+        # animat geoms: contype 1 / conaffinity 0; arena geoms: 1 / 1 -> animat against arena only (the self-collisions are explicit pairs)
+        common = dict(name=f'geom_{g}', pos=v(m.geom_pos[g]), quat=v(m.geom_quat[g]), friction=v(m.geom_friction[g]), solref=v(m.geom_solref[g]),
+                      solimp=v(m.geom_solimp[g]), condim='3', margin='0', contype='1', conaffinity='1' if ground else '0')
+        if t == GEOM_MESH:                           # convex mesh: its hull vertices as an inline mesh asset
             a0, n = int(m.geom_vertadr[g]), int(m.geom_vertnum[g])
             ET.SubElement(asset, 'mesh', name=f'mesh_{g}', vertex=v(np.asarray(m.mesh_vert[a0:a0 + n]).ravel()))
             ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type='mesh', mesh=f'mesh_{g}', **common)
             continue
-        size = {GEOM_PLANE: [1, 1, 0.1], 1: [1, 1, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
+        if t == GEOM_HFIELD:                         # mjModel.hfield_*: nrow x ncol samples in [0, 1] scaled by size[2] (+ base size[3])
+            data = np.asarray(m.hfield_data, float).reshape(int(m.hfield_nrow), int(m.hfield_ncol))
+            hs = np.asarray(m.hfield_size, float)
+            # MuJoCo normalises the elevation data of an asset to [0, 1] and scales by size[2]: the model's data may be
+            # signed (the reference stores 2 (image - 0.5), task.py:115), so the asset is written as (data - min) / range with the
+            # elevation range as size[2] and the geom lowered by -min * size[2]: the same surface
+            lo, hi = float(data.min()), float(data.max())
+            rng_ = hi - lo if hi > lo else 1.0
+            ET.SubElement(asset, 'hfield', name='hfield_0', nrow=str(int(m.hfield_nrow)), ncol=str(int(m.hfield_ncol)),
+                          size=v([hs[0], hs[1], hs[2]*rng_ if hs[2]*rng_ > 0 else 1e-9, max(hs[3], 1e-9)]),
+                          elevation=v(((data - lo)/rng_).ravel()))
+            from ..model import quat2mat
+            off = quat2mat(np.asarray(m.geom_quat[g], float)) @ np.array([0.0, 0.0, lo*hs[2]])
+            hcommon = dict(common, pos=v(np.asarray(m.geom_pos[g], float) + off))
+            ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type='hfield', hfield='hfield_0', **hcommon)
+            continue
+        size = {GEOM_PLANE: [0, 0, 0.1], GEOM_SPHERE: m.geom_size[g][:1], GEOM_CAPSULE: m.geom_size[g][:2], GEOM_CYLINDER: m.geom_size[g][:2], GEOM_BOX: m.geom_size[g][:3]}[t]
         ET.SubElement(elems[int(m.geom_bodyid[g])], 'geom', type=gtypes[t], size=v(size), **common)
+    if not len(asset):
+        root.remove(asset)
+    if int(getattr(m, 'npair', 0)):                  # explicit self-collision pairs (mjcf.py:1012-1033)
+        con = ET.SubElement(root, 'contact')
+        for p_ in range(int(m.npair)):
+            mu = float(m.pair_friction[p_])
+            ET.SubElement(con, 'pair', name=f'pair_{p_}', geom1=f'geom_{int(m.pair_geom1[p_])}', geom2=f'geom_{int(m.pair_geom2[p_])}', condim='3',
+                          friction=v([mu, mu, 0.005, 0.0001, 0.0001]), solref=v(m.pair_solref[p_]), solimp=v(m.pair_solimp[p_]), margin='0', gap='0')
     if m.nu:
         act = ET.SubElement(root, 'actuator')
         for a in range(m.nu):
