@@ -388,7 +388,8 @@ def main():
                          'traffic_note': ('HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
                                           f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}') if traffic is not None else
                                          (f'null: {stale}' if stale else 'null: no PMC summary of this workload / batch size under profiles/'),
-                         'kernel': ('fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)' if info['threads_per_env'] == 32
+                         'kernel': (('fmj_step_cons2_kernel<true, MAXD> (two envs per wave; envs beyond 64 constraint rows finish in fmj_step_kernel<true, MAXD, CONS>)'
+                                     if sim.physics.has_constraints else 'fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)') if info['threads_per_env'] == 32
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b['full'],

@@ -58,7 +58,7 @@ class CFusedArgs(ctypes.Structure):
                 ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
                 ('row_stride_contacts', ctypes.c_int64),
                 ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP),
-                ('env_order', _VP)]
+                ('env_order', _VP), ('substeps', ctypes.c_int32), ('substep_links', ctypes.c_int32)]
 
 
 # every symbol include/fmj.h declares: name -> (restype, argtypes)
@@ -111,12 +111,14 @@ def build_id() -> str:
 
 
 _lib = None
-ABI_VERSION = 4         # FMJ_ABI_VERSION of include/fmj.h
+ABI_VERSION = 5         # FMJ_ABI_VERSION of include/fmj.h
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:
     """Compile csrc/fmj_hip.hip for gfx950 into csrc/libfmj_hip.so (hipcc cross-compiles without a GPU).
-    ``defines`` / ``out`` build a variant next to it (scripts/stamps.py: ``-DFMJ_STAMPS``)."""
+    ``defines`` / ``out`` build a variant next to it (scripts/stamps.py: ``-DFMJ_STAMPS``).
+    Development shortcut: ``FMJ_DEV_MAXD=20,28`` recompiles only the host object and the step-kernel objects of those register
+    row lengths and links them with the objects a previous build left in csrc/_obj (possibly stale: never for a commit)."""
     src = os.path.join(CSRC, 'fmj_hip.hip')
     target = SO_PATH if out is None else os.path.join(CSRC, out)
     deps = [src, HEADER] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith('.inc')]
@@ -125,25 +127,30 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
         # one object per register row length (the step-kernel instantiations) + one for the host side, compiled in
         # parallel, then linked: the single translation unit took 2.3 min, this takes the time of the slowest object
         import concurrent.futures
-        import tempfile
         flags = ['--offload-arch=gfx950', '-O3', '-fno-slp-vectorize', '-mllvm', '-pragma-unroll-threshold=131072', '-fPIC'] + list(defines)
-        with tempfile.TemporaryDirectory(prefix='fmj_build_') as tmp:
-            jobs = [(os.path.join(tmp, 'host.o'), [])] + [(os.path.join(tmp, f'k{n}.o'), [f'-DFMJ_TU_MAXD={n}'])
-                                                          for n in range(4, 65, 4)]      # 36 .. 64: the unconstrained one-env kernel only
+        objdir = os.path.join(CSRC, '_obj' if out is None else '_obj_' + os.path.splitext(out)[0])
+        os.makedirs(objdir, exist_ok=True)
+        dev = [int(x) for x in os.environ.get('FMJ_DEV_MAXD', '').split(',') if x.strip()]
+        jobs = [(os.path.join(objdir, 'host.o'), [])] + [(os.path.join(objdir, f'k{n}.o'), [f'-DFMJ_TU_MAXD={n}'])
+                                                         for n in range(4, 65, 4)]      # 36 .. 64: the unconstrained one-env kernel only
+        if dev:
+            todo = [j for j in jobs if not j[1] or int(j[1][0].split('=')[1]) in dev or not os.path.exists(j[0])]
+        else:
+            todo = jobs
 
-            def cc(job):
-                obj, defs = job
-                cmd = ['hipcc'] + flags + defs + ['-c', src, '-o', obj]
-                if verbose:
-                    print(' '.join(cmd))
-                subprocess.check_call(cmd)
-                return obj
-            with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
-                objs = list(ex.map(cc, jobs))
-            cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', target]
+        def cc(job):
+            obj, defs = job
+            cmd = ['hipcc'] + flags + defs + ['-c', src, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             subprocess.check_call(cmd)
+            return obj
+        with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
+            list(ex.map(cc, todo))
+        cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[0] for j in jobs] + ['-o', target]
+        if verbose:
+            print(' '.join(cmd))
+        subprocess.check_call(cmd)
     return target
 
 

@@ -156,14 +156,16 @@ class NetworkController(AnimatController):
     fusable = True
     tape = True
 
-    def __init__(self, model, network, n_envs, env_phase=None, drive=None, device='cuda:0'):
+    def __init__(self, model, network, n_envs, env_phase=None, drive=None, device='cuda:0', timestep=None):
         from . import _lib
         names = [model.joint_names[model.actuator_jntid[a]] for a in range(model.nu)
                  if model.actuator_tags[a] == 'position']
         super().__init__({ControlType.POSITION: names, ControlType.VELOCITY: [], ControlType.TORQUE: []})
         assert network.nu == model.nu
         self.network, self.n_envs, self.nu, self.device = network, n_envs, model.nu, torch.device(device)
-        self.timestep = float(model.timestep)
+        # the network advances once per ITERATION (task.py:288-346 calls the controller on full steps only): with sub-steps pass
+        # simulation_options.timestep, the model's own timestep being timestep / num_sub_steps (mjcf.py:1187-1192)
+        self.timestep = float(model.timestep if timestep is None else timestep)
         self._lib = _lib.load()
         import ctypes
         self._ctx = ctypes.c_void_p()

@@ -101,7 +101,9 @@ struct DevModel {
   float ls_tolerance;
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
   int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
+  int cons2_ok;                        // constraints + two envs per wave (fmj_cons2.inc): limits / ground contacts, pyramidal cone, PGS
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
+  float dual_taddm[3];                 // m_total + armature: the same block of M itself (fmj_cons2.inc factors both)
   const struct DualRound* dual_rounds; // [dual_nround] elimination rounds of the two-env kernel (fmj_dual2.inc)
   int dual_nround;
   const struct DualRound* rounds1;     // [nround1] the same for the one-env kernel (lane = dof, all dofs)
@@ -158,6 +160,7 @@ struct StepArgs {
   float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
   float* qacc_warmstart; float* contact; int* ncon; float* contacts_rows; float inv_newtons;
   int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
+  int substeps, sub_links;    // fused: physics steps per iteration (>= 1); sub-steps write links-only rows + drag (include/fmj.h)
   long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc, row_stride_contacts;
   int n_contact_rows, n_pairs; const int* geom_sensor; const int* pairs;
   float* links; float* joints; float* xfrc; float* xfrc_applied_out;
@@ -168,6 +171,7 @@ struct StepArgs {
   const float* w_amp; const float* w_lag; const float* w_env; float w_freq;
   float* ctrl_out;            // fused + wave controller: ctrl of the launch's last step (physics.data.ctrl)
   const int* env_order;       // one-env kernel: env of workgroup b (NULL: b); heavier envs first shortens a launch's tail
+  int* resume;                // [n_envs] or NULL: steps of this launch already completed per env (written by fmj_cons2.inc, read by the one-env kernel)
   float* dbg_H; float* dbg_qfrc;   // fmj_forward_debug: rows of H = M + diag(armature + h damping) [n_envs][nv][rs], qfrc_smooth [n_envs][nv]
   float* dbg_efc; float* dbg_pgs;  // fmj_step_debug: constraint rows after the solve [n_envs][maxefc][8], dual-cost improvement per PGS sweep [n_envs][solver_iterations]
 };
@@ -179,7 +183,8 @@ struct fmj_ctx {
   int device, n_envs;
   DevModel dm;
   std::vector<void*> allocs;
-  size_t lds_bytes, lds_bytes_dual2;
+  size_t lds_bytes, lds_bytes_dual2, lds_bytes_cons2;
+  int* d_resume;              // [n_envs] hand-over of the two-env constraint kernel to the one-env kernel
   int dual_wps;               // waves per SIMD the dual2 build is registered for: 4, or 3 when the batch cannot fill more (FMJ_WPS overrides)
   fmj_sensor_layout_t layout;
   // host copies needed later
@@ -963,6 +968,10 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
 #define M (*Mp)
 #define A (*Ap)
   const int env = A.env_order ? gptr(A.env_order)[blockIdx.x] : blockIdx.x;
+  // Hand-over from the two-env constraint kernel (fmj_cons2.inc): resume[env] steps of this launch are done; this kernel runs the
+  // rest from the launch-boundary state that kernel stored (the row of the first remaining iteration is already written).
+  const int step0 = (CONS && A.resume) ? gptr(A.resume)[env] : 0;
+  if (step0 >= A.n_steps && CONS && A.resume) return;
   const int lane = threadIdx.x;
   const int nb = M.nbody, nv = M.nv, nq = M.nq, nu = M.nu;
   constexpr int RS = MAXD;                     // row stride of H == register row length (dispatch guarantees M.rs == MAXD)
@@ -1041,7 +1050,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
   // The fields of the last forward pass are not carried through LDS: the links row of iteration it + 1 and its drag
   // (ExperimentTask.before_step, reference task.py:168-186) are emitted by the step that computes them (step it); the row of
   // the launch's first iteration comes from the fields the caller hands over.
-  if (FUSED && !frozen && A.n_steps > 0) {
+  if (FUSED && !frozen && A.n_steps > 0 && !(CONS && A.resume)) {
     const int cl = lane < nb ? lane : 0;
     const float* p = glob(A.xpos) + (size_t)env * nb * 3 + cl * 3;
     const float4 q = *(const float4*)(glob(A.xquat) + (size_t)env * nb * 4 + cl * 4);
@@ -1061,21 +1070,30 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
 #endif
 
   const int lane_outer = lane;
+  // sub-steps (include/fmj.h, reference task.py:168-186,348-369): `sub` = index of this physics step inside its iteration
+  // (0 = the full step), `itm` = iterations completed in this launch
+  int sub = 0, itm = 0;
+  if (step0 > 0) { const int S0 = A.substeps > 1 ? A.substeps : 1; itm = step0 / S0; sub = step0 - itm * S0; }
 #pragma unroll 1
-  for (int step = 0; step < A.n_steps; step++) {
+  for (int step = step0; step < A.n_steps; step++) {
     if (frozen) break;
     asm volatile("" : "+s"(Mp), "+s"(Ap));       // arguments are re-read from the kernarg segment in every step
     // per-lane LDS/global addresses are recomputed every step instead of being hoisted and spilled
     const int lane = opaque(lane_outer);
-    const int it = A.iteration0 + step;
+    const int it = A.iteration0 + itm;
     const bool last = step == A.n_steps - 1;
+    const int S_sub = A.substeps;
+    const bool full = sub == 0;
+    const int nsub = sub + 1 >= S_sub ? 0 : sub + 1;           // the next physics step: its sub index, whether it is a full step,
+    const bool nfull = nsub == 0;                               // and task.iteration as its before_step will see it: the reference
+    const int nit = (nfull ? it + 1 : it) + ((nsub >= 1 && nsub >= S_sub - 1) ? 1 : 0);   // advances it after sub-step S - 2 (task.py:352-355)
     const int blo = opaque(bl), dlo = opaque(dl);
     // the lane's depth / subtree size are laundered too: every per-lane predicate made from them (lvl < ddepth for 20
     // levels, the ancestor tests of the sweeps) is loop-invariant and was hoisted into SGPR pairs - ~100 of them, all spilled
     const int ddepth = opaque(ddepth_o), dsub = opaque(dsub_o);
     // ============ before_step (reference task.py:168-186) ============
     STAMP(0);   // emit links + drag
-    if (CONS && FUSED && A.do_readout && A.contacts_rows) {     // cycontacts2data from the carried contact list
+    if (CONS && FUSED && A.do_readout && A.contacts_rows && full) {     // cycontacts2data from the carried contact list
       const int index = it % A.buffer_size;
       for (int row = lane; row < A.n_contact_rows; row += 64)
         contact_row(CT, cy_ncon, row, glob(A.geom_sensor), A.n_pairs, glob(A.pairs), A.inv_newtons, A.inv_meters,
@@ -1083,7 +1101,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       WSYNC();
     }
     // joint part (physics.py:500-524): needs the CURRENT qpos/qvel
-    if (FUSED && A.do_readout) {
+    if (FUSED && A.do_readout && full) {
       const int4 di = DTABI(dlo, 0);
       const float4 dp = DTAB(dlo, 1);
       if (isd && dp.w != 0.f && di.w >= 0) {
@@ -1256,9 +1274,9 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
     // ---- sensors of this (pre-integration) state; they are next iteration's link data (mj_step lag)
     {
       const v3 linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
-      if (FUSED && !last) {      // next iteration's links row and drag (xf is consumed above, in this step's F)
-        const int4 ci2 = BTABI(blo, 8);
-        emit_links_and_drag(M, A, env, it + 1, isb, false, ci2.z, ci2.w, xp, xq, xi, linvel, cv.r, xf);
+      if (FUSED && !last && (nfull || A.sub_links)) {      // the next before_step's links row and drag (xf is consumed above, in this step's F);
+        const int4 ci2 = BTABI(blo, 8);                     // a sub-step that writes no row keeps the drag force it has
+        emit_links_and_drag(M, A, env, nit, isb, false, ci2.z, ci2.w, xp, xq, xi, linvel, cv.r, xf);
       }
       if (last && lane < nb) {
         float* p = glob(A.xpos) + (size_t)env * nb * 3 + lane * 3; p[0] = xp.x; p[1] = xp.y; p[2] = xp.z;
@@ -1346,7 +1364,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
         float cbase = 0.f;
         if (FUSED && A.controller == 1) {
           // phase in cycles kept in fp64 so long runs keep the argument exact (task.py:290: time = iteration*timestep)
-          double cyc = (double)A.w_freq * ((double)it * (double)M.h);
+          double cyc = (double)A.w_freq * ((double)it * ((double)M.h * (double)S_sub));   // task.py:290: time = iteration * timestep (of an iteration)
           cyc -= floor(cyc);
           cbase = 6.283185307179586f * (float)cyc + gptr(A.w_env)[env];
         }
@@ -1357,7 +1375,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
             const float4 p = ATAB(ai, 0), lim = ATAB(ai, 1);
             float c;
             if (FUSED && A.controller == 1) { const float amp = gptr(A.w_amp)[src]; c = amp != 0.f ? amp * sinf(cbase - gptr(A.w_lag)[src]) : 0.f; }
-            else c = A.ctrl ? gptr(A.ctrl)[(size_t)step * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;
+            else c = A.ctrl ? gptr(A.ctrl)[(size_t)itm * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;      // one ctrl row per iteration
             c = fminf(fmaxf(c, lim.x), lim.y);
             float f = p.x * c + p.y + p.z * qj + p.w * qd;
             f = fminf(fmaxf(f, lim.z), lim.w);
@@ -1749,6 +1767,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       }
     }
     if (__any((warn & FMJ_WARN_BADQPOS) != 0)) frozen = true;   // no row of the next iteration is emitted from a bad position
+    sub = nsub; itm += nfull ? 1 : 0;
     WSYNC();
     STAMP(11);  // Euler
   }
@@ -1779,6 +1798,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
 #undef M
 #undef A
 #include "fmj_dual2.inc"
+#include "fmj_cons2.inc"
 
 // ---------------------------------------------------------------------------------------------
 // Build layout: this file is compiled once per register row length with -DFMJ_TU_MAXD=<4..32> (only the step-kernel
@@ -1791,7 +1811,15 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
 #if FMJ_TU_MAXD > 32        // rows longer than 32: the unconstrained one-env kernel only (FMJ_MAXD_DEEP)
   (void)cons; (void)dual;
   return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, false> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, false>;
+#elif defined(FMJ_DEV_CONS2_ONLY)      // development build: only the two-env constraint kernel and its one-env fallback (compile time)
+  if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_cons2_kernel<false, FMJ_TU_MAXD>;
+  if (cons == 1 && dual == 0) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
+  return nullptr;
 #else
+  if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_cons2_kernel<false, FMJ_TU_MAXD>;
+  if (dual == 16 + 2) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4, true>;      // fused launches with sub-steps
+  if (dual == 16 + 4) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2, true>;
+  if (dual == 16 + 3) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3, true>;
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
@@ -1967,7 +1995,7 @@ static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, c->dual_wps == 2 ? 4 : (c->dual_wps == 3 ? 3 : 2));
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, (c->dual_wps == 2 ? 4 : (c->dual_wps == 3 ? 3 : 2)) + ((fused && A.substeps > 1) ? 16 : 0));
     hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual2, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
@@ -1975,6 +2003,19 @@ static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) 
   }
   if (c->dm.cons && (!A.qacc_warmstart || !A.contact || !A.ncon))
     return set_err(FMJ_ERR_ARG, "fmj_data: qacc_warmstart, contact and ncon are required for models with limits / contacts");
+  if (c->dm.cons2_ok && A.integrate && !(fused && A.do_drag)) {
+    // two envs per wave (fmj_cons2.inc), then the one-env kernel for whatever that kernel handed over (resume[env] < n_steps: an
+    // env with more rows than a wave holds on chip); envs it completed cost the second launch one early exit each
+    StepArgs A2 = A;
+    A2.resume = c->d_resume;
+    hipLaunchKernelGGL(tu_kernel(c->dm.rs, fused, 0, 5), dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_cons2, (hipStream_t)stream, c->dm, A2);
+    hipError_t e2 = hipGetLastError();
+    if (e2 != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("two-env constraint kernel launch: ") + hipGetErrorString(e2));
+    hipLaunchKernelGGL(pick_kernel(c, fused), dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A2);
+    e2 = hipGetLastError();
+    if (e2 != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e2));
+    return FMJ_OK;
+  }
   hipLaunchKernelGGL(pick_kernel(c, fused), dim3(c->n_envs), dim3(64), c->lds_bytes, (hipStream_t)stream, c->dm, A);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("step kernel launch: ") + hipGetErrorString(e));
@@ -2356,8 +2397,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     const int t0 = D.root_free ? 3 : 0;
     const char* envv = getenv("FMJ_DUAL");
     D.dual_t0 = t0;
-    D.dual_ok = !cons && nb <= 32 && nv - t0 <= 32 && !(envv && envv[0] == '0');
+    const bool halves_ok = nb <= 32 && nv - t0 <= 32 && !(envv && envv[0] == '0');      // bodies / lane dofs of an env fit half a wave
+    D.dual_ok = !cons && halves_ok;
+    // the two-env constraint kernel covers what BASELINE configs[3] needs: limits + ground contacts of sphere / capsule / box / cylinder
+    // geoms on ONE ground geom, pyramidal cone, PGS; everything else (pairs, meshes, Newton / CG, the elliptic cone) keeps the one-env kernel
+    D.cons2_ok = cons && halves_ok && D.rs <= FMJ_MAXD && m->solver == FMJ_SOLVER_PGS && !dual_instead && m->cone == FMJ_CONE_PYRAMIDAL && m->npair == 0 &&
+                 !any_mesh && nplane <= 1 && m->ngeom <= 32;
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
+    for (int t = 0; t < 3; t++) D.dual_taddm[t] = t < t0 ? (float)(mtot + m->dof_armature[t]) : 1.0f;
     {   // elimination rounds of the one-env kernel (lane = dof): dofs grouped by depth, deepest first, <= 3 per round
       std::vector<DualRound> rounds;
       std::vector<unsigned long long> ancm(nv, 0ull), descm(nv, 0ull);
@@ -2412,7 +2459,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     {   // elimination rounds: lane dofs grouped by depth, deepest first, at most three per round
       const int nd = nv - t0 > 0 ? nv - t0 : 0;
       std::vector<DualRound> rounds;
-      if (D.dual_ok) {
+      if (D.dual_ok || D.cons2_ok) {
         std::vector<unsigned long long> ancm(nd, 0ull), descm(nd, 0ull);
         int maxdep = 0;
         for (int i = 0; i < nd; i++) {
@@ -2447,7 +2494,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
         for (int i = 0; i < 32; i++) {
           uint8_t* row = (uint8_t*)&ancl[(size_t)i * (D.rs / 4)];
           for (int l = 0; l < D.rs; l++) row[l] = (uint8_t)(4 * i);
-          if (D.dual_ok && i < nd) {
+          if ((D.dual_ok || D.cons2_ok) && i < nd) {
             if (ddepth[i + t0] > md) md = ddepth[i + t0];
             for (int a = m->dof_parentid[i + t0]; a >= t0; a = m->dof_parentid[a]) row[ddepth[a]] = (uint8_t)(4 * (a - t0));
           }
@@ -2487,6 +2534,13 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   D.nfl = L.nfl;
   c->lds_bytes = (size_t)L.total * sizeof(float);
   c->lds_bytes_dual2 = D.dual_ok ? (size_t)(2 * lds2_layout(nb, nv, nq, D.rs, D.dual_t0).total + r4(nb * D.anc_stride) / 4) * sizeof(float) : 0;
+  c->lds_bytes_cons2 = 0; c->d_resume = nullptr;
+  if (D.cons2_ok) {
+    c->lds_bytes_cons2 = (size_t)lds3_layout(nb, nv, nq, D.rs, D.dual_t0, D.max_contacts, D.anc_stride).total * sizeof(float);
+    void* pr = nullptr;
+    if (c->lds_bytes_cons2 > 64 * 1024 || hipMalloc(&pr, (size_t)n_envs * sizeof(int)) != hipSuccess) D.cons2_ok = 0;      // (cannot happen within the size limits above)
+    else { c->allocs.push_back(pr); c->d_resume = (int*)pr; (void)hipMemset(pr, 0, (size_t)n_envs * sizeof(int)); }
+  }
   {
     hipDeviceProp_t prop;
     int n_cu = 256;
@@ -2513,8 +2567,8 @@ int fmj_get_sensor_layout(const fmj_ctx* c, fmj_sensor_layout_t* out) {
 
 int fmj_kernel_info(const fmj_ctx* c, int32_t* lds_bytes_per_env, int32_t* threads_per_env) {
   if (!c) return set_err(FMJ_ERR_ARG, "fmj_kernel_info: NULL ctx");
-  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)(c->dm.dual_ok ? c->lds_bytes_dual2 / 2 : c->lds_bytes);
-  if (threads_per_env) *threads_per_env = c->dm.dual_ok ? 32 : 64;   // the integrating step packs two envs per wave when it can
+  if (lds_bytes_per_env) *lds_bytes_per_env = (int32_t)(c->dm.dual_ok ? c->lds_bytes_dual2 / 2 : (c->dm.cons2_ok ? c->lds_bytes_cons2 / 2 : c->lds_bytes));
+  if (threads_per_env) *threads_per_env = (c->dm.dual_ok || c->dm.cons2_ok) ? 32 : 64;   // the integrating step packs two envs per wave when it can
   return FMJ_OK;
 }
 
@@ -2598,7 +2652,7 @@ static int fill_data(const fmj_ctx* c, const fmj_data* d, StepArgs* A, bool need
   A->time = d->time; A->status = d->status; A->n_envs = c->n_envs;
   A->qacc_warmstart = d->qacc_warmstart; A->contact = d->contact; A->ncon = d->ncon;
   A->inv_meters = A->inv_velocity = A->inv_angvel = A->inv_torques = A->newtons = A->torques = 1.0f;
-  A->buffer_size = 1;
+  A->buffer_size = 1; A->substeps = 1;
   return FMJ_OK;
 }
 
@@ -2669,7 +2723,9 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   if (a->controller == 1 && (!a->wave.amplitude || !a->wave.phase_lag || !a->wave.env_phase)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: wave controller arrays missing");
   if (a->controller != 0 && a->controller != 1) return set_err(FMJ_ERR_ARG, "fmj_step_fused: unknown controller");
   A.integrate = 1;
-  A.n_steps = a->n_steps; A.iteration0 = a->iteration0; A.buffer_size = a->buffer_size; A.do_readout = a->do_readout;
+  A.substeps = a->substeps > 1 ? a->substeps : 1; A.sub_links = (A.substeps > 1 && a->substep_links) ? 1 : 0;
+  if ((long long)a->n_steps * A.substeps > 0x7fffffffLL) return set_err(FMJ_ERR_ARG, "fmj_step_fused: n_steps * substeps overflows");
+  A.n_steps = a->n_steps * A.substeps; A.iteration0 = a->iteration0; A.buffer_size = a->buffer_size; A.do_readout = a->do_readout;
   A.do_drag = a->do_drag; A.controller = a->controller; A.ctrl_step_stride = a->ctrl_step_stride;
   A.row_stride_links = a->row_stride_links; A.row_stride_joints = a->row_stride_joints; A.row_stride_xfrc = a->row_stride_xfrc;
   A.links = a->rows_base.links; A.joints = a->rows_base.joints; A.xfrc = a->rows_base.xfrc;
@@ -2681,7 +2737,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
   A.ctrl_out = a->controller == 1 ? a->ctrl_out : nullptr;
-  A.env_order = c->dm.dual_ok ? nullptr : a->env_order;
+  A.env_order = c->dm.dual_ok ? nullptr : a->env_order;      // the two-env constraint kernel pairs neighbours of the order: similar row counts
   HIP_TRY(hipSetDevice(c->device));
   return launch_step(c, true, A, stream);
 }

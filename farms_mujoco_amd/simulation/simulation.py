@@ -97,15 +97,17 @@ class Simulation:
         self.task.after_step(self.physics)
 
     def step_fused(self, n_steps: int):
-        """Run ``n_steps`` full iterations inside ONE launch (fmj_step_fused): ring-buffer readout, drag,
-        xfrc glue, controller and mj_step, with state resident in LDS/registers between steps."""
+        """Run ``n_steps`` full iterations (``substeps`` physics steps each) inside ONE launch (fmj_step_fused): ring-buffer
+        readout, drag, xfrc glue, controller and mj_step, with state resident in LDS/registers between steps."""
         task, phys = self.task, self.physics
         assert task.fusable()
-        n_steps = min(n_steps, task.n_iterations - task.iteration)
+        assert task.sim_iteration % task.substeps == 0, 'a fused launch starts on a full step'
+        n_steps = min(n_steps, task.n_iterations - task.sim_iteration//task.substeps)
         if n_steps <= 0:
             return 0
         a = _lib.CFusedArgs()
-        a.n_steps, a.iteration0, a.buffer_size = n_steps, task.iteration, task.buffer_size
+        a.n_steps, a.iteration0, a.buffer_size = n_steps, task.sim_iteration//task.substeps, task.buffer_size
+        a.substeps, a.substep_links = task.substeps, int(task.substeps_links)
         a.do_readout = 1
         sens = task.data.sensors
         a.rows_base.links = sens.links.array.data_ptr()
@@ -137,13 +139,17 @@ class Simulation:
             a.wave.frequency = c.frequency
             a.ctrl_out = phys.data.ctrl.data_ptr()       # callbacks reading physics.data.ctrl see the last step's command
         if phys.has_constraints and self.order_by_contacts:
-            # envs with the most contacts (the slowest to step) are launched first instead of wherever they sit
+            # envs with the most contacts (the slowest to step) are launched first instead of wherever they sit; the two-env constraint
+            # kernel steps entries 2b and 2b + 1 of the order in one wave: neighbours have similar row counts (one PGS sweep length
+            # for both; pairing the heaviest with the lightest instead was measured: no difference in the launch time)
             self._env_order = torch.argsort(phys.data.ncon, descending=True, stable=True).to(torch.int32)
             a.env_order = self._env_order.data_ptr()
         _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
                                             ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
-        task.iteration += n_steps
-        task.sim_iteration += n_steps
+        # the counters as n_steps * substeps calls of after_step leave them (task.py:351-355: with sub-steps the iteration is
+        # advanced one sub-step early, except that nothing follows the launch's last full step yet)
+        task.sim_iteration += n_steps*task.substeps
+        task.iteration = (task.sim_iteration + 1)//task.substeps if task.substeps > 1 else task.sim_iteration
         return n_steps
 
     def run(self, fused=None, chunk=None):
@@ -155,7 +161,7 @@ class Simulation:
         try:
             if fused:
                 chunk = chunk or task.buffer_size
-                while task.iteration < task.n_iterations:
+                while task.sim_iteration < task.sim_iterations:
                     self.step_fused(min(chunk, task.buffer_size))
                     self.physics.check_invalid_state()      # per chunk: a bad env is already frozen on the device
             else:

@@ -157,7 +157,11 @@ class ExperimentTask:
 
     def before_step(self, action, physics):
         """Operations before physics step (reference task.py:168-186)."""
-        assert self.iteration < self.n_iterations
+        # the reference asserts iteration < n_iterations here; with sub-steps its own counter reaches n_iterations one sub-step
+        # before the run ends (task.py:352-355) and only dm_control's reset-on-first-step, which costs the run its last
+        # environment step (SURVEY Appendix C.13), keeps that assert from firing.  run() here advances all n_iterations * substeps
+        # steps, so the bound is stated on the counter that does not run ahead
+        assert self.sim_iteration < self.sim_iterations
         full_step = not self.sim_iteration % self.substeps
         if full_step or self.substeps_links:
             self.update_sensors(physics=physics, links_only=not full_step)
@@ -244,7 +248,8 @@ class ExperimentTask:
     # ---- fused fast path ------------------------------------------------------------------------------
     def fusable(self):
         """True when every per-step hook has a device implementation, so the whole before_step + mj_step
-        sequence can run inside one launch (fmj_step_fused)."""
+        sequence can run inside one launch (fmj_step_fused) - sub-steps included: the kernel sequences full steps and
+        sub-steps, links-only rows and the iteration counter as before_step / after_step do (include/fmj.h)."""
         cbs_ok = all(getattr(cb, 'fusable', False) for cb in self._callbacks)
         ctl_ok = self._controller is None or getattr(self._controller, 'fusable', False)
-        return cbs_ok and ctl_ok and self.substeps == 1
+        return cbs_ok and ctl_ok

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMJ_ABI_VERSION 4
+#define FMJ_ABI_VERSION 5
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -207,7 +207,7 @@ typedef struct fmj_data {
   float* xpos;               /* [n_envs,nbody,3] */
   float* xquat;              /* [n_envs,nbody,4] wxyz */
   float* xipos;              /* [n_envs,nbody,3] */
-  float* sensordata;         /* [n_envs,nsensordata] layout: fmj_sensor_layout()          */
+  float* sensordata;         /* [n_envs,nsensordata] layout: fmj_get_sensor_layout()      */
   float* qacc;               /* [n_envs,nv] may be NULL */
   float* time;               /* [n_envs]   may be NULL */
   int32_t* status;           /* [n_envs]   warning bits, OR-accumulated                   */
@@ -358,7 +358,18 @@ int fmj_contacts2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows, con
  * (ExperimentTask.before_step + Environment.step, reference task.py:168-186, simulation.py:155-156).
  * rows_base point at ring index 0; row_stride_* = elements between ring indices.
  * controller: 0 = ctrl tape (ctrl + s*ctrl_step_stride), 1 = built-in travelling-wave
- * position controller (see fmj_wave_controller). */
+ * position controller (see fmj_wave_controller).
+ * Sub-steps (ABI 5; reference mjcf.py:1187-1192,1329: the model's timestep is options.timestep / num_sub_steps, and
+ * simulation.py:148-156 runs n_iterations * substeps environment steps): with substeps = S > 1 an iteration is S calls of
+ * mj_step; n_steps counts ITERATIONS (the launch starts on a full step and runs n_steps * S physics steps).  Only the first
+ * sub-step of an iteration is a "full step" (task.py:175): it writes the links / joints / contact rows, runs the drag and the
+ * controller (time = iteration * S * model timestep; a ctrl tape holds one row per iteration); the ctrl and - unless
+ * substep_links - the drag force then stay as they are for the remaining sub-steps.  With substep_links != 0 (some callback
+ * asked for sub-steps, task.py:63,176,181: here the swimming callback) every sub-step also writes a links-only row and
+ * recomputes the drag from it, at the ring index of task.iteration AS THE REFERENCE COUNTS IT: after_step advances the
+ * iteration when (sim_iteration + 1) % S == 0 (task.py:352-355), i.e. after sub-step S - 2 of each group, so the sub-steps
+ * j >= S - 1 of iteration m write row m + 1 (overwritten by the next full step) and, for S >= 3, sub-steps 1 .. S - 2 overwrite
+ * the links part of row m itself (reproduced, not fixed). */
 typedef struct fmj_wave_controller {
   const float* amplitude;   /* [nu] DEVICE, per actuator (0 for non-position actuators) */
   const float* phase_lag;   /* [nu] DEVICE */
@@ -386,6 +397,9 @@ typedef struct fmj_fused_args {
   const int32_t* env_order; /* [n_envs] DEVICE or NULL: a permutation of the envs; workgroup b of the one-env kernel steps
                                env_order[b].  Results do not depend on it; listing the envs with the most contacts first
                                keeps them from starting last and setting the launch time (constraint models) */
+  /* ABI 5 */
+  int32_t substeps;         /* physics steps per iteration (simulation_options.num_sub_steps; task.py:61,64-66); <= 1: one */
+  int32_t substep_links;    /* != 0: sub-steps write links-only rows and recompute the drag (a callback with substep=True) */
 } fmj_fused_args;
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);

@@ -1687,6 +1687,7 @@ typedef struct fused_job {
   double meaninertia;
   int n_xfrc;                       /* rows per env of the xfrc array */
   double* contacts; int n_contact_rows, n_keys; const int32_t* keys;   /* contact sensor rows [buffer, n_envs, n_rows, 12] or NULL */
+  int substeps, substep_links;      /* ExperimentTask.substeps (task.py:61) and substeps_links (task.py:63): see the loop below */
 } fused_job;
 
 static void* fused_worker(void* arg) {
@@ -1709,38 +1710,51 @@ static void* fused_worker(void* arg) {
       forward(m, w, qpos, qvel, NULL, J->qpos_spring + (size_t)e * m->nq, NULL, NULL);
       w->disable_actuation = 0;
     }
-    for (int s = 0; s < J->n_steps; s++) {
-      int it = J->iteration0 + s, index = it % J->buffer_size;
+    /* ExperimentTask's own counters, restated literally (task.py:49,64-66,168-186,348-369): sim_iteration counts environment
+     * steps, `iteration` is advanced by after_step when (sim_iteration + 1) % substeps == 0 AFTER the increment - i.e. after
+     * sub-step substeps - 2 of every group - and every write of before_step goes to the ring index of
+     * `iteration` as it stands at that moment.  n_steps counts iterations: n_steps * substeps environment steps. */
+    const int S = J->substeps > 1 ? J->substeps : 1;
+    int sim_iteration = 0, iteration = J->iteration0;
+    for (int s = 0; s < J->n_steps * S; s++) {
+      const int full_step = (sim_iteration % S) == 0;                       /* task.py:175 */
+      const int sensors_now = full_step || J->substep_links;               /* task.py:176 */
+      const int links_only = !full_step;
+      int it = iteration, index = it % J->buffer_size;                     /* task.py:158 */
       double* lrow = tmp_links;
-      if (J->contacts && J->do_readout) {   /* cycontacts2data on the contacts of the last forward pass (physics.py:543-545) */
+      if (J->contacts && J->do_readout && sensors_now && !links_only) {   /* cycontacts2data on the contacts of the last forward pass (physics.py:533-545) */
         export_contacts(w, con);
         contacts2data_one(w->ncon, con, J->n_contact_rows, J->n_keys, J->keys, J->units[0], J->units[1],
                           J->contacts + ((size_t)index * J->n_envs + e) * J->n_contact_rows * FMJ_CONTACT_SIZE);
       }
-      if (J->do_readout) {
+      if (J->do_readout && sensors_now) {
         lrow = J->links + ((size_t)index * J->n_envs + e) * J->n_links * FMJ_LINK_SIZE;
         double* jrow = J->joints + ((size_t)index * J->n_envs + e) * J->n_joints * FMJ_JOINT_SIZE;
         physics2data_one(m, qpos, qvel, xpos, xquat, xipos, sd, J->n_links, J->links_body, J->n_joints,
-                         J->joints_jnt, J->units, 0, lrow, jrow);
-      } else if (J->do_drag) {
+                         J->joints_jnt, J->units, links_only, lrow, jrow);
+      } else if (J->do_drag && sensors_now) {
         physics2data_one(m, qpos, qvel, xpos, xquat, xipos, sd, J->n_links, J->links_body, 0, NULL, J->units, 1, lrow, NULL);
       }
-      if (J->do_drag) {
+      if (J->do_drag && sensors_now) {                                     /* the swimming callback: task.py:180-182 (full step, or its substep flag) */
         double* xrow = J->xfrc + ((size_t)index * J->n_envs + e) * J->n_xfrc * FMJ_XFRC_SIZE;
         fmjo_drag(1, J->n_links, J->n_xfrc, nb, J->ns, J->sw_links_index, J->sw_xfrc_index, J->sw_body_index,
                   J->coefficients, J->masses, J->heights, J->densities, J->surface, J->water_vel, J->viscosity,
                   J->gravity, J->use_buoyancy, J->units[1], J->units[2], lrow, xrow, xa);
       }
-      if (J->controller == 1) {
-        double t = it * m->timestep;   /* task.py:290 */
-        for (int a = 0; a < m->nu; a++)
-          ctrl[a] = J->wave_amplitude[a] * sin(2 * M_PI * J->wave_frequency * t - J->wave_phase_lag[a] + J->wave_env_phase[e]);
-      } else if (J->ctrl) {
-        memcpy(ctrl, J->ctrl + (size_t)s * J->ctrl_step_stride + (size_t)e * m->nu, m->nu * sizeof(double));
+      if (full_step) {                                                     /* step_control: task.py:184-186,288-346 */
+        if (J->controller == 1) {
+          double t = it * (m->timestep * S);   /* task.py:290: iteration * timestep, the timestep of an iteration (the model's is timestep / substeps: mjcf.py:1187-1192) */
+          for (int a = 0; a < m->nu; a++)
+            ctrl[a] = J->wave_amplitude[a] * sin(2 * M_PI * J->wave_frequency * t - J->wave_phase_lag[a] + J->wave_env_phase[e]);
+        } else if (J->ctrl) {
+          memcpy(ctrl, J->ctrl + (size_t)(s / S) * J->ctrl_step_stride + (size_t)e * m->nu, m->nu * sizeof(double));
+        }
       }
       warn |= step_one(m, w, qpos, qvel, ctrl, J->qpos_spring + (size_t)e * m->nq, J->do_drag ? xa : NULL, sd);
       memcpy(xpos, w->xpos, 3 * nb * sizeof(double)); memcpy(xquat, w->xquat, 4 * nb * sizeof(double));
       memcpy(xipos, w->xipos, 3 * nb * sizeof(double));
+      sim_iteration++;                                                     /* after_step: task.py:351-355 */
+      if (((sim_iteration + 1) % S) == 0) iteration++;
     }
     if (J->status) J->status[e] |= warn;
   }
@@ -1759,7 +1773,7 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
                    double surface, const double* water_vel, double viscosity, double gravity, int use_buoyancy,
                    const double* units, const double* wave_amplitude, const double* wave_phase_lag,
                    const double* wave_env_phase, double wave_frequency, int n_threads,
-                   int n_xfrc, double* contacts, int n_contact_rows, int n_keys, const int32_t* keys) {
+                   int n_xfrc, double* contacts, int n_contact_rows, int n_keys, const int32_t* keys, int substeps, int substep_links) {
   if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > n_envs) n_threads = n_envs;
@@ -1782,6 +1796,7 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
     J->wave_amplitude = wave_amplitude; J->wave_phase_lag = wave_phase_lag; J->wave_env_phase = wave_env_phase;
     J->wave_frequency = wave_frequency; J->meaninertia = mi;
     J->n_xfrc = n_xfrc > 0 ? n_xfrc : n_links; J->contacts = contacts; J->n_contact_rows = n_contact_rows; J->n_keys = n_keys; J->keys = keys;
+    J->substeps = substeps; J->substep_links = substeps > 1 ? substep_links : 0;
     if (n_threads == 1) fused_worker(J); else pthread_create(&th[t], NULL, fused_worker, J);
   }
   if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);

@@ -15,7 +15,7 @@ src = f'gpurun_out/prof_{tag}'
 bench = json.loads(open(f'{src}/bench.json').read().strip().splitlines()[-1])
 envs, steps = bench['config']['envs_per_gpu'], bench['config']['steps_per_launch']
 b_alg = bench['roofline']['algorithmic_bytes_per_env_step']
-dual = 'dual' in bench['roofline']['kernel']
+dual = 'two envs per wave' in bench['roofline']['kernel']
 waves = (envs + 1)//2 if dual else envs
 out = [head, f'source: scripts/profile.sh {tag} (rocprofv3 --pmc passes around: python bench.py --no-cpu-baseline --steps 500 --warmup 500 ...)',
        f'bench line of the same build: {bench["value"]/1e6:.1f} M env-steps/s, launch {bench["launch_ms"]["median"]:.3f} ms (median of {bench["launch_ms"]["n"]})',

@@ -818,3 +818,56 @@ def test_mesh_on_heightfield_and_fused_rows(oracle):
     scale = np.abs(want[..., :9]).max()
     assert scale > 0.05 and np.abs(rows[..., :9] - want[..., :9]).max()/scale < 3e-2
     assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3
+
+
+def test_two_env_kernel_modes_do_not_depend_on_the_partner(oracle, monkeypatch):
+    """The two-env constraint kernel (fmj_cons2.inc, round 4): what an env computes depends neither on the mode its rows were solved
+    in - PAIR (both envs of the wave have <= 32 rows: solved at once), SOLO (one has 33..64: one after the other) - nor on the env it
+    shares its wave with; an env with more than 64 rows retires from the wave ALONE and is finished by the one-env kernel, bitwise
+    as if that kernel had stepped it from the start (FMJ_DUAL=0).  All of it within tolerance of the oracle."""
+    import torch
+    from farms_mujoco_amd.physics import BatchedPhysics
+    m = _walker()
+    rng = np.random.default_rng(11)
+    base = np.tile(m.qpos0, (1, 1))[0]
+
+    def state(z, seed):
+        r = np.random.default_rng(seed)
+        q = base.copy(); q[7:] += r.uniform(-0.05, 0.05, m.nq - 7); q[2] = z
+        return q
+    # candidates from standing on the feet down to lying on the belly; classes by the oracle's row count of the FIRST step
+    cands = [state(z, 100 + i) for i, z in enumerate((0.045, 0.03, 0.0175, 0.0165, 0.0155, 0.0145, 0.012, 0.01))]
+    nefc = [oracle.forward_debug(m, q.astype(np.float32).astype(np.float64), np.zeros(m.nv), ctrl=np.zeros(m.nu))['nefc'] for q in cands]
+    light = [q for q, ne in zip(cands, nefc) if 0 < ne <= 32][:2]
+    medium = [q for q, ne in zip(cands, nefc) if 32 < ne <= 64][:2]
+    heavy = [q for q, ne in zip(cands, nefc) if ne > 64][:1]
+    assert len(light) == 2 and len(medium) == 2 and len(heavy) == 1, nefc
+    L, L2, Md, Md2, Hv = light[0], light[1], medium[0], medium[1], heavy[0]
+    T = 25
+    import os
+
+    def run(qs):
+        phys = BatchedPhysics(m, len(qs))
+        assert phys.kernel_info()['threads_per_env'] == (32 if os.environ.get('FMJ_DUAL', '1') != '0' else 64)
+        q32, v32 = _set(phys, np.array(qs), np.zeros((len(qs), m.nv)))
+        phys.step(T)
+        torch.cuda.synchronize()
+        d = phys.data
+        assert int((d.status & ~8).abs().sum()) == 0
+        return (d.qpos.cpu().numpy().copy(), d.qvel.cpu().numpy().copy(), d.qacc_warmstart.cpu().numpy().copy(), d.contact.cpu().numpy().copy(),
+                d.ncon.cpu().numpy().copy(), d.sensordata.cpu().numpy().copy(), q32, v32)
+    same = lambda a, i, b, j: all(np.array_equal(a[k][i], b[k][j]) for k in range(6))
+    r_ll, r_lm, r_lh, r_l = run([L, L2]), run([L, Md]), run([L, Hv]), run([L])
+    assert same(r_ll, 0, r_lm, 0) and same(r_ll, 0, r_lh, 0) and same(r_ll, 0, r_l, 0), 'a light env changed with its partner'
+    r_mm, r_mh, r_ml = run([Md, Md2]), run([Md, Hv]), run([Md2, L])
+    assert same(r_mm, 0, r_lm, 1) and same(r_mm, 0, r_mh, 0) and same(r_mm, 1, r_ml, 0), 'an env with 33..64 rows changed with its partner'
+    r_hh = run([Hv, Hv])
+    assert same(r_hh, 0, r_lh, 1) and same(r_hh, 0, r_mh, 1) and same(r_hh, 0, r_hh, 1)
+    monkeypatch.setenv('FMJ_DUAL', '0')            # the one-env kernel from the first step on: what a retired env must reproduce bitwise
+    r_one = run([Hv, L])
+    assert same(r_one, 0, r_hh, 0), 'a retired env is not what the one-env kernel computes'
+    # ... and the two kernels agree with each other and with the oracle to fp32 tolerance on the light env
+    assert _relerr(r_one[0][1], r_ll[0][0]) < 2e-5
+    for res in (r_ll, r_lm, r_lh, r_mm):
+        ref = oracle.step(m, res[6], res[7], ctrl=np.zeros((len(res[6]), m.nu)), n_steps=T)
+        assert _relerr(res[0], ref['qpos']) < 2e-4, _relerr(res[0], ref['qpos'])

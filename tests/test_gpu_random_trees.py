@@ -126,12 +126,15 @@ def test_random_tree_vs_oracle(oracle, seed, two_per_wave, monkeypatch):
     assert err('qpos') < 2e-3, (seed, 'qpos50', err('qpos'))
 
 
-@pytest.mark.parametrize('seed', range(100, 112))
-def test_random_tree_with_limits_and_contacts(oracle, seed):
+@pytest.mark.parametrize('seed,two_per_wave', [(s, True) for s in range(100, 112)] + [(s, False) for s in range(100, 112, 2)])
+def test_random_tree_with_limits_and_contacts(oracle, seed, two_per_wave, monkeypatch):
     """The constraint path on random trees: limited hinges, sphere / capsule / box / cylinder geoms over a plane that cuts
-    through the tree; contact lists, constraint forces and the state after one and after 30 steps vs the oracle."""
+    through the tree; contact lists, constraint forces and the state after one and after 30 steps vs the oracle.  Every tree here has
+    <= 32 bodies: it runs in the two-env constraint kernel (fmj_cons2.inc) by default, FMJ_DUAL=0 sends it through the one-env kernel."""
     import torch
     from farms_mujoco_amd.physics import BatchedPhysics
+    if not two_per_wave:
+        monkeypatch.setenv('FMJ_DUAL', '0')
     m = random_tree(seed, contacts=True)
     if m is None or m.nv == 0:
         pytest.skip('degenerate draw')
@@ -145,7 +148,7 @@ def test_random_tree_with_limits_and_contacts(oracle, seed):
     qvel = rng.normal(size=(n, m.nv))*0.2
     ctrl = rng.uniform(-0.4, 0.4, (n, max(m.nu, 1)))[:, :m.nu]
     phys = BatchedPhysics(m, n)
-    assert phys.kernel_info()['threads_per_env'] == 64
+    assert phys.kernel_info()['threads_per_env'] == (32 if two_per_wave else 64)
     d = phys.data
     f32 = lambda a: torch.as_tensor(a, dtype=torch.float32)
     d.qpos[:] = f32(qpos); d.qvel[:] = f32(qvel)

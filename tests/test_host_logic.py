@@ -68,7 +68,8 @@ def test_fusable_rules():
     assert _task().fusable()
     assert _task(callbacks=[DevCb()]).fusable()
     assert not _task(callbacks=[_Recorder()]).fusable()        # arbitrary host callbacks need per-step launches
-    assert not _task(callbacks=[DevCb()], substeps=2).fusable()
+    assert _task(callbacks=[DevCb()], substeps=2).fusable()     # round 4: the fused kernel sequences sub-steps itself (include/fmj.h)
+    assert not _task(callbacks=[_Recorder(substep=True)], substeps=2).fusable()
 
 
 def test_units_and_options():

@@ -85,7 +85,7 @@ def test_header_symbols_exported():
     lib = _lib.load()
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.fmj_abi_version() == _lib.ABI_VERSION == 4
+    assert lib.fmj_abi_version() == _lib.ABI_VERSION == 5
     assert _lib.sc('LINK_SIZE') == 20 and _lib.sc('XFRC_TORQUE') == 3 and lib.fmj_sc(b'nope') == -1
 
 
