@@ -55,7 +55,7 @@ def test_step_parity_other_morphologies(oracle, maker):
             fl = oracle.step(m, q32, qvel, ctrl=tape_t.cpu().numpy().astype(np.float64), n_steps=T, ctrl_step_stride=n*m.nu, n_threads=8)
         flo = _relerr(fl['qpos'], ref['qpos'])
         print(maker, 'fp32-storage floor of the same rollout:', flo)
-        assert err < max(1e-4, 6*flo) and err < 1e-3
+        assert err < max(1e-4, 6*flo) and err < 1e-3      # INTEGRATION.md "Model size": beyond nv ~ 60 the 1e-4 statement is 1e-3
 
 
 def _bucket_sim(maker, n, T, ring, env_offset=0, seed=9, twins=()):
@@ -98,6 +98,13 @@ def _bucket_oracle(oracle, sim, m, T, ring, envs):
     return oracle.run_fused(m, st, T, swim=h.swim_dict(), water=water, buffer_size=ring, controller=1, wave=wave, n_threads=8)
 
 
+# Absolute caps next to the "6 x floor" rule (round 4): the per-component metric divides by the size of each entry, and the entries of a
+# long eel's rows that are nearly zero (lateral velocities of the head links, torques of 1e-9 N m on the tail) carry relative errors of
+# tens of percent in ANY fp32 run - the fp64 oracle with its mass matrix rounded to fp32 shows 5 - 18 % there.  What such a run can be
+# held to in absolute terms is the whole-tensor figure max |a - b| / max |b|:
+CAP48 = dict(qpos=2e-3, links=1.5e-2, xfrc=8e-3)      # measured 7.6e-4, 5.4e-3, 2.6e-3; the fp32-storage floor run: 3.8e-4, 1.7e-3, 8.7e-4
+
+
 def test_fused_swim_of_a_long_eel(oracle):
     """The fused loop (rows, drag, wave controller) of an eel of 48 joints - a dof chain of 54: the MAXD 56 build of the
     unconstrained one-env kernel - against the oracle's fused loop, bounds against the fp32-storage floor like the mixed batch."""
@@ -116,8 +123,10 @@ def test_fused_swim_of_a_long_eel(oracle):
     groups = dict(qpos=qpos_groups(m), links=link_row_groups(), xfrc=[slice(0, 3), slice(3, 6)])
     for k in got:
         err = group_relerr(got[k], ref[k], groups[k]); fl = group_relerr(flo[k], ref[k], groups[k])
-        print('eel48', k, 'err', err, 'fp32-storage floor', fl)
+        whole, whole_fl = _relerr(got[k], ref[k]), _relerr(flo[k], ref[k])
+        print('eel48', k, 'per-component err', err, 'fp32-storage floor', fl, ' whole-tensor err', whole, 'floor', whole_fl)
         assert err < 6*fl + 1e-6, (k, err, fl)
+        assert whole < CAP48[k], (k, whole)
     assert np.abs(sens.links.array.cpu().numpy()[-1, :, :, 14:17]).max() > 1e-3      # it swims
 
 
