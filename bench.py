@@ -47,7 +47,7 @@ def algorithmic_bytes_per_env_step(m, sim=None, workload='swim', sims=None):
     return dict(core=core, log=log, cons=cons, full=core + log + cons)
 
 
-def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', morphology='salamander33'):
+def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', morphology='salamander33', substeps=1):
     """Fused simulation of one morphology.  workload 'swim' = BASELINE configs[1] (water, drag + buoyancy, no contact);
     'walk' = configs[3] (plane contacts + joint limits, PGS, no water)."""
     import torch
@@ -64,9 +64,9 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
             if workload == 'walk_elliptic':
                 m.cone = mm.CONES['elliptic']
     else:
-        m = getattr(mm, morphology)()
+        m = getattr(mm, morphology)() if substeps == 1 else getattr(mm, morphology)(timestep=1e-3/substeps)
     qpos, qvel, psi = mm.synthetic_batch(m, n_envs, seed=0, env_offset=env_offset)
-    opts = SimulationOptions(timestep=m.timestep, n_iterations=n_iterations)
+    opts = SimulationOptions(timestep=m.timestep*substeps, n_iterations=n_iterations, num_sub_steps=substeps)
     ctl = WaveController(m, psi, device=device)
     kw = {}
     if workload.startswith('walk'):
@@ -208,6 +208,31 @@ def other_workloads(n_envs, chunk, device):
                                'BASELINE configs[4]: half eels, half centipedes, one bucket (launch, HIP stream) per morphology, side by side'}
         del sims, batch
     return res
+
+
+def api_paths(n_envs, chunk, device):
+    """The same swimming batch through the API a caller uses (reference simulation.py:148-161): ``Simulation.run()`` - the fused path
+    with its status read-back and host sync per chunk, which the headline loop (``step_fused`` back to back) never pays -, the same
+    with two sub-steps per iteration (mjcf.py:1187-1192), and the unfused path (``before_step`` / ``after_step`` from the host: one
+    launch per operator and physics step - what a run with host callbacks costs).  env-steps/s; an env-step = one mj_step of one env."""
+    import torch
+    out = {}
+    for name, n_it, sub, fused in (('run_fused', 3000, 1, True), ('run_fused_substeps2', 1500, 2, True), ('run_unfused', 300, 1, False)):
+        sim, m, _ = build_sim(n_envs, n_it, chunk, 0, device, substeps=sub)
+        warm = 3*chunk if fused else 20
+        sim.task.n_iterations = warm; sim.task.sim_iterations = warm*sub
+        sim.run(fused=fused)                                   # warm-up through the same call
+        sim.task.n_iterations = n_it; sim.task.sim_iterations = n_it*sub
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        sim.run(fused=fused)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        steps = (n_it - warm)*sub
+        out[name] = {'value': n_envs*steps/dt, 'unit': 'env-steps/s', 'iterations': n_it - warm, 'substeps': sub,
+                     'call': f'Simulation.run(fused={fused}), ring of {chunk} rows' + ('' if fused else ': fmj_physics2data + fmj_drag + ctrl write + fmj_step(1) per step')}
+        del sim
+    return out
 
 
 def spawn_ranks(args):
@@ -406,6 +431,11 @@ def main():
                 out['other_workloads'] = other_workloads(n_envs, chunk, device)
             except Exception as e:
                 out['other_workloads'] = {'error': repr(e)}
+        if world == 1 and not args.no_extras and args.workload == 'swim':
+            try:
+                out['api_paths'] = api_paths(n_envs, chunk, device)
+            except Exception as e:
+                out['api_paths'] = {'error': repr(e)}
         if world == 1 and not args.no_cpu_baseline and args.workload == 'swim':
             try:
                 out['cpu_baseline'] = cpu_baseline(m, sim)
