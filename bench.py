@@ -345,12 +345,19 @@ def main():
     t0 = time.perf_counter()
     evs = run(K*R)
     torch.cuda.synchronize()
+    dt_own = time.perf_counter() - t0               # this rank's own finish time, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     from farms_mujoco_amd.sharding import max_over_ranks
     dt = max_over_ranks(dt, device=device if args.dist_backend == 'nccl' else None)
+    rank_s = [dt_own]
+    if world > 1:                                   # the spread over ranks behind the max (a slow GPU or a late launch shows here)
+        t = torch.zeros(world, dtype=torch.float64, device=device if args.dist_backend == 'nccl' else 'cpu')
+        t[rank] = dt_own
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        rank_s = [float(x) for x in t.cpu()]
     for s_ in sims:
         s_.physics.check_invalid_state()
 
@@ -387,6 +394,8 @@ def main():
             'metric': f'env-steps/sec, {names[args.workload]} \u00d7{n_envs} envs, 1/2/4/8 MI355X',
             'value': n_envs*world*K*R/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
             'repeats': R, 'steps_timed': K*R, 'timed_region_s': dt,
+            'rank_seconds': {'min': min(rank_s), 'max': max(rank_s), 'mean': float(np.mean(rank_s)),
+                             'note': 'each rank\'s own time from the common start barrier to the end of its last launch; timed_region_s adds the closing barrier'},
             'ms_per_step': dt/(K*R)*1e3, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
             'dtype': 'f32', 'data': 'synthetic', 'build_id': build,
             'config': {'workload': {'swim': f'BASELINE configs[1]: {n_envs}x salamander-33 swimming per GPU (nbody={m.nbody}, '

@@ -86,6 +86,7 @@ SYMBOLS = {
     'fmj_forward_debug': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.c_int32, _VP, _I, _VP, _VP]),
     'fmj_step_debug': (ctypes.c_int, [_VP, ctypes.POINTER(CData), _VP, _VP, _VP]),
     'fmj_constraint_info': (ctypes.c_int, [_VP, _I, _I, _I]),
+    'fmj_solver_info': (ctypes.c_int, [_VP, _I, _I, _I]),
     'fmj_drag': (ctypes.c_int, [_VP, ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits), _VP, _VP]),
     'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
                                         ctypes.c_int32, _VP]),
@@ -154,6 +155,9 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
     return target
 
 
+OPTIONAL_IN_AB_BASE = ('fmj_solver_info',)      # queries only (physics.py tolerates their absence under FMJ_SO)
+
+
 def load():
     """dlopen the HIP library and bind every declared symbol. Raises if it has not been built."""
     global _lib
@@ -165,7 +169,12 @@ def load():
                        'There is no CPU fallback for the product path.')
     lib = ctypes.CDLL(SO_PATH)
     for name, (res, args) in SYMBOLS.items():
-        fn = getattr(lib, name)      # AttributeError if the .so does not export a declared symbol
+        try:
+            fn = getattr(lib, name)  # AttributeError if the .so does not export a declared symbol
+        except AttributeError:
+            if os.environ.get('FMJ_SO') and name in OPTIONAL_IN_AB_BASE:      # scripts/ab.sh: an older build under today's host code
+                continue
+            raise
         fn.restype = res
         fn.argtypes = args
     if lib.fmj_abi_version() != ABI_VERSION:

@@ -101,6 +101,7 @@ struct DevModel {
   float ls_tolerance;
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
   int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
+  int implicitfast;                    // integrator = implicitfast: the velocity gains of unclamped actuators join the damping on the diagonal of H (include/fmj.h)
   int cons2_ok;                        // constraints + two envs per wave (fmj_cons2.inc): limits / ground contacts, pyramidal cone, PGS
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
   float dual_taddm[3];                 // m_total + armature: the same block of M itself (fmj_cons2.inc factors both)
@@ -185,6 +186,7 @@ struct fmj_ctx {
   std::vector<void*> allocs;
   size_t lds_bytes, lds_bytes_dual2, lds_bytes_cons2;
   int* d_resume;              // [n_envs] hand-over of the two-env constraint kernel to the one-env kernel
+  int solver_requested;       // fmj_model.solver as handed in (fmj_create may run the dual solver instead: fmj_solver_info)
   int dual_wps;               // waves per SIMD the dual2 build is registered for: 4, or 3 when the batch cannot fill more (FMJ_WPS overrides)
   fmj_sensor_layout_t layout;
   // host copies needed later
@@ -1334,6 +1336,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
     STAMP(6);   // S
     // ---- Q: qfrc_smooth, buf = (I_s w, m v(s))  (lane = dof)
     float qfrc = 0.f;
+    float dvel = 0.f;                               // implicitfast: velocity gains of this dof's unclamped actuators
     float af0 = 0.f, af1 = 0.f, af2 = 0.f, af3 = 0.f;
     const float4 d_prm = DTAB(dlo, 1);             // armature, damping, qposadr bits, hinge/slide flag
     const int4 d_act = DTABI(dlo, 2);               // first actuator, count, joint sensor slot
@@ -1378,6 +1381,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
             else c = A.ctrl ? gptr(A.ctrl)[(size_t)itm * A.ctrl_step_stride + (size_t)env * nu + src] : 0.f;      // one ctrl row per iteration
             c = fminf(fmaxf(c, lim.x), lim.y);
             float f = p.x * c + p.y + p.z * qj + p.w * qd;
+            if (M.implicitfast && !A.disable_actuation && f > lim.z && f < lim.w) dvel -= p.w;      // d force / d qvel of an unclamped actuator (mjd_actuator_vel)
             f = fminf(fmaxf(f, lim.z), lim.w);
             if (A.disable_actuation) f = 0.f;
             if (a == 0) af0 = f; else if (a == 1) af1 = f; else if (a == 2) af2 = f; else af3 = f;
@@ -1417,7 +1421,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       const v3 gi = add3(bf.r, cross(sc, bf.l));
       const float mii = dot3(cd.r, gi) + dot3(cd.l, bf.l);
       hdg_m = isd ? mii + d_prm.x : 1.f;
-      hdg_h = isd ? mii + (d_prm.x + M.h * d_prm.y) : 1.f;
+      hdg_h = isd ? mii + (d_prm.x + M.h * (d_prm.y + dvel)) : 1.f;
       const int maxdep = M.maxdep1;
 #pragma unroll
       for (int g = 0; g < MAXD / 4; g++) {
@@ -1736,6 +1740,9 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
     if (isd) {
       if (!(fabsf(my_qacc) <= 1e10f)) warn |= FMJ_WARN_BADQACC;      // mj_checkAcc
       if (!(fabsf(nvel) <= 1e10f)) warn |= FMJ_WARN_BADQVEL;
+      // the root position this step would commit is tested BEFORE anything is committed (the translational dofs of a free root are
+      // dofs 0..2 at qpos 0..2): a step that raises BADQPOS leaves qpos, qvel and time exactly at the previous step's values
+      if (M.root_free && lane < 3 && A.integrate && !(fabsf(QP[lane] + M.h * nvel) <= 1e10f)) warn |= FMJ_WARN_BADQPOS;
     }
     if (__any((warn & FMJ_WARN_FREEZE) != 0)) frozen = true;         // the state stays at its last finite values
     if (isd && !frozen) {
@@ -1817,7 +1824,8 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   return nullptr;
 #else
   if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_cons2_kernel<false, FMJ_TU_MAXD>;
-  if (dual == 16 + 2) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4, true>;      // fused launches with sub-steps
+  if (dual >= 16 && !fused) return (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4, true>;      // single steps with the rare options (implicitfast): one register tier is enough, they are launch-bound
+  if (dual == 16 + 2) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4, true>;      // fused launches with sub-steps / implicitfast
   if (dual == 16 + 4) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2, true>;
   if (dual == 16 + 3) return (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3, true>;
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
@@ -1995,7 +2003,7 @@ static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
   if (c->dm.dual_ok && A.integrate) {      // two envs per wave (fmj_dual2.inc); fmj_forward keeps the single-env kernel
-    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, (c->dual_wps == 2 ? 4 : (c->dual_wps == 3 ? 3 : 2)) + ((fused && A.substeps > 1) ? 16 : 0));
+    step_kernel_t k = tu_kernel(c->dm.rs, fused, 0, (c->dual_wps == 2 ? 4 : (c->dual_wps == 3 ? 3 : 2)) + (((fused && A.substeps > 1) || c->dm.implicitfast) ? 16 : 0));      // + 16: the instantiation with the rare options (sub-steps, implicitfast)
     hipLaunchKernelGGL(k, dim3((c->n_envs + 1) / 2), dim3(64), c->lds_bytes_dual2, (hipStream_t)stream, c->dm, A);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return set_err(FMJ_ERR_HIP, std::string("dual step kernel launch: ") + hipGetErrorString(e));
@@ -2099,7 +2107,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON && m->solver != FMJ_SOLVER_CG) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: solver must be FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON");
   if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path covers limits and ground contacts: no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
-  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG (the PGS kernel implements the pyramidal cone only)");
+  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG: its PGS kernel solves scalar (pyramid) rows, one per lane; MuJoCo's elliptic PGS (ray update + friction QCQP per contact) is in the oracle only");
   // Pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 (the reference's arena has friction 0, mjcf.py:1202, so a contact's friction is
   // its link's - 1e-5 after MuJoCo's clamp when the link has none) a contact force is a residual too small for an fp32 primal
   // iteration (see fmj_cons_rows.inc on the friction-0 pairs).  Such a model is solved on the dual problem throughout: the PGS
@@ -2112,7 +2120,9 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     for (int g = 0; g < m->ngeom; g++)
       if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) * isq < 1e-3) dual_instead = true;
   }
-  if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip iterations are not implemented");
+  if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip_iterations > 0: MuJoCo's noslip post-pass (PGS on the friction rows without regularisation) is not implemented; run with noslip_iterations = 0 (the reference's default, mjcf.py:1392-1397)");
+  if (m->integrator != FMJ_INT_EULER && m->integrator != FMJ_INT_IMPLICITFAST)
+    return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: integrator must be FMJ_INT_EULER or FMJ_INT_IMPLICITFAST (RK4 is four forward passes per step; implicit keeps the Coriolis derivatives, a non-symmetric matrix outside this path's tree-sparse factorisation)");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
@@ -2167,6 +2177,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   HIP_TRY(hipSetDevice(device));
 
   fmj_ctx* c = new fmj_ctx();
+  c->solver_requested = cons ? m->solver : FMJ_SOLVER_PGS;
   c->device = device; c->n_envs = n_envs; c->nbody = nb; c->nv = nv; c->nu = nu; c->njnt = nj;
   c->d_btab = nullptr; c->d_dtab = nullptr; c->d_links_body = nullptr; c->d_joints_dof = nullptr;
   DevModel& D = c->dm;
@@ -2292,6 +2303,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     // the HBM constraint path keeps A in rows of AG_LD floats and three 64-row slots per lane (fmj_cons_rows.inc)
     if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
   }
+  D.implicitfast = m->integrator == FMJ_INT_IMPLICITFAST;
   D.solver_iterations = dual_instead ? 10 * m->solver_iterations : m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.cone = cons ? m->cone : FMJ_CONE_PYRAMIDAL;
   D.solver = (cons && !dual_instead) ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
@@ -2700,6 +2712,14 @@ int fmj_constraint_info(const fmj_ctx* c, int32_t* maxefc, int32_t* max_contacts
   if (maxefc) *maxefc = c->dm.maxefc;
   if (max_contacts) *max_contacts = c->dm.max_contacts;
   if (solver_iterations) *solver_iterations = c->dm.solver_iterations;
+  return FMJ_OK;
+}
+
+int fmj_solver_info(const fmj_ctx* c, int32_t* requested, int32_t* effective, int32_t* iterations) {
+  if (!c) return set_err(FMJ_ERR_ARG, "fmj_solver_info: NULL ctx");
+  if (requested) *requested = c->solver_requested;
+  if (effective) *effective = c->dm.solver;
+  if (iterations) *iterations = c->dm.solver_iterations;
   return FMJ_OK;
 }
 

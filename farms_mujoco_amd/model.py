@@ -268,10 +268,11 @@ _CMODEL_FIELDS = (
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
          ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)] +
         [('solver', ctypes.c_int32), ('cone', ctypes.c_int32), ('ls_iterations', ctypes.c_int32), ('noslip_iterations', ctypes.c_int32),
-         ('ls_tolerance', ctypes.c_double), ('noslip_tolerance', ctypes.c_double)]
+         ('ls_tolerance', ctypes.c_double), ('noslip_tolerance', ctypes.c_double), ('integrator', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
 )
 SOLVERS = {'pgs': 0, 'cg': 1, 'newton': 2}          # mjtSolver (include/fmj.h FMJ_SOLVER_*)
 CONES = {'pyramidal': 0, 'elliptic': 1}            # mjtCone
+INTEGRATORS = {'euler': 0, 'rk4': 1, 'implicit': 2, 'implicitfast': 3}      # mjtIntegrator (include/fmj.h FMJ_INT_*: Euler and implicitfast are implemented)
 
 
 class _CModel(ctypes.Structure):
@@ -474,6 +475,7 @@ class Model:
         m.cone = CONES[str(b.options.get('cone', 'pyramidal')).lower()]
         m.ls_iterations = int(b.options.get('ls_iterations', 50)); m.ls_tolerance = float(b.options.get('ls_tolerance', 0.01))
         m.noslip_iterations = int(b.options.get('noslip_iterations', 0)); m.noslip_tolerance = float(b.options.get('noslip_tolerance', 1e-6))
+        m.integrator = INTEGRATORS[str(b.options.get('integrator', 'Euler')).lower()]
 
         # swimming links, in body order (reference drag.pyx:353-385)
         m.swimming = []
@@ -552,6 +554,7 @@ class Model:
         c.solver = int(getattr(self, 'solver', 0)); c.cone = int(getattr(self, 'cone', 0))
         c.ls_iterations = int(getattr(self, 'ls_iterations', 50)); c.ls_tolerance = float(getattr(self, 'ls_tolerance', 0.01))
         c.noslip_iterations = int(getattr(self, 'noslip_iterations', 0)); c.noslip_tolerance = float(getattr(self, 'noslip_tolerance', 1e-6))
+        c.integrator = int(getattr(self, 'integrator', 0))
         c.hfield_nrow, c.hfield_ncol = int(getattr(self, 'hfield_nrow', 0)), int(getattr(self, 'hfield_ncol', 0))
         c.hfield_size = (ctypes.c_double*4)(*np.asarray(getattr(self, 'hfield_size', np.zeros(4)), float))
         hd = getattr(self, 'hfield_data', None)

@@ -63,6 +63,17 @@ class BatchedPhysics:
         self.data.ncon = z(n, dtype=torch.int32)
         self.data.xquat[:, :, 0] = 1.0
         self.data.qpos_spring[:] = torch.as_tensor(m.qpos_spring, dtype=torch.float32)
+        # the solver that actually runs (fmj_solver_info): fmj_create swaps a primal solver for the dual one on near-frictionless contacts
+        rq, ef, it = ctypes.c_int32(), ctypes.c_int32(), ctypes.c_int32()
+        if hasattr(self._lib, 'fmj_solver_info') and self._lib.fmj_solver_info.argtypes:     # absent only from an A/B base build (FMJ_SO)
+            _lib.check(self._lib.fmj_solver_info(self._ctx, ctypes.byref(rq), ctypes.byref(ef), ctypes.byref(it)))
+        names = {0: 'PGS', 1: 'CG', 2: 'Newton'}
+        self.solver_requested, self.solver_effective, self.solver_budget = names[rq.value], names[ef.value], it.value
+        if rq.value != ef.value:
+            import warnings
+            warnings.warn(f'solver={self.solver_requested!r} was requested, but some ground contact has friction / sqrt(impratio) < 1e-3 (rows an fp32 '
+                          f'primal iteration cannot resolve): the model is solved on the dual problem instead - {self.solver_effective} to the '
+                          f'solver tolerance, up to {self.solver_budget} sweeps per step (same minimiser; include/fmj.h: fmj_solver_info)', stacklevel=2)
         self.links_body = np.arange(1, m.nbody, dtype=np.int32)
         self.joints_jnt = np.nonzero(m.jnt_type != JNT_FREE)[0].astype(np.int32)
         self.reset()

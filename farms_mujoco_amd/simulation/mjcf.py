@@ -44,19 +44,30 @@ def get_local_transform(parent_pose, child_pose):
     return local[:3, -1], local[:3, :3]
 
 
-def check_supported_options(simulation_options):
-    """The step runs semi-implicit Euler with PGS (pyramidal cone) or Newton / CG (pyramidal or elliptic cone); the reference forwards
-    ``simulation_options.integrator / cone / solver`` to MuJoCo's option block (mjcf.py:1342-1365), so any other request would
-    silently run different physics: refuse it."""
+def check_supported_options(simulation_options, compile_only=False):
+    """What of ``simulation_options.integrator / cone / solver / noslip_iterations`` (forwarded to MuJoCo's option block by the reference,
+    mjcf.py:1342-1403) the HIP step implements; anything else would silently run different physics, so it is refused HERE with the
+    reason (and again by ``fmj_create``):
+      integrator  Euler (with MuJoCo's implicit joint damping) and implicitfast.  RK4 is four forward passes per step; ``implicit``
+                  keeps the Coriolis derivatives, a non-symmetric matrix outside the tree-sparse L'DL of this path.
+      solver/cone PGS with the pyramidal cone; Newton / CG with the pyramidal or the elliptic cone.  PGS with the elliptic cone (MuJoCo's
+                  ray update + friction QCQP per contact) exists in the oracle only: the device PGS solves scalar rows, one per lane.
+      noslip      MuJoCo's post-pass on the friction rows without regularisation is not implemented (oracle and device)."""
     if simulation_options is None:
         return
-    for name, supported in (('integrator', ('euler',)), ('cone', ('pyramidal', 'elliptic')), ('solver', ('pgs', 'cg', 'newton'))):
+    for name, supported, why in (
+            ('integrator', ('euler', 'implicitfast'), 'MuJoCo also has RK4 (four forward passes per step) and implicit (Coriolis derivatives: a non-symmetric '
+                                                     'matrix outside this path\'s tree-sparse factorisation)'),
+            ('cone', ('pyramidal', 'elliptic'), ''), ('solver', ('pgs', 'cg', 'newton'), '')):
         value = getattr(simulation_options, name, None)
         if value is not None and str(value).lower() not in supported:
-            raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {" / ".join(supported)} only '
-                                      '(Euler with implicit joint damping; PGS with the pyramidal cone, Newton / CG with either cone)')
+            raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {" / ".join(supported)} only' + (f' ({why})' if why else ''))
     if str(getattr(simulation_options, 'cone', 'pyramidal')).lower() == 'elliptic' and str(getattr(simulation_options, 'solver', 'PGS')).lower() == 'pgs':
-        raise NotImplementedError("simulation_options.cone='elliptic' needs solver='Newton' or 'CG' on the HIP path (its PGS kernel implements the pyramidal cone)")
+        raise NotImplementedError("simulation_options.cone='elliptic' needs solver='Newton' or 'CG' on the HIP path: its PGS kernel solves scalar (pyramid) rows, "
+                                  "one per lane; MuJoCo's elliptic PGS (ray update + friction QCQP per contact) is in the oracle only")
+    if not compile_only and int(getattr(simulation_options, 'noslip_iterations', 0) or 0) > 0:     # the compiler still forwards it (MJCF export)
+        raise NotImplementedError('simulation_options.noslip_iterations > 0: MuJoCo\'s noslip post-pass (PGS on the friction rows without regularisation) is '
+                                  'not implemented in the oracle or on the device; run with noslip_iterations = 0 (the reference\'s own default, mjcf.py:1392-1397)')
 
 
 def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
@@ -79,7 +90,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
     act_vel = dict(ctrllimited=kwargs.pop('act_vel_ctrllimited', False), ctrlrange=kwargs.pop('act_vel_ctrlrange', [-1e6, 1e6]),
                    forcelimited=kwargs.pop('act_vel_forcelimited', False), forcerange=kwargs.pop('act_vel_forcerange', [-1e6, 1e6]))
     assert not kwargs, kwargs
-    check_supported_options(simulation_options)
+    check_supported_options(simulation_options, compile_only=True)
 
     timestep = 1e-3
     gravity = [0.0, 0.0, -9.81]
@@ -94,6 +105,7 @@ def sdf2model(sdf: ModelSDF, **kwargs) -> Model:
         b.options['cone'] = str(getattr(simulation_options, 'cone', 'pyramidal'))     # mjcf.py:1342-1347
         b.options['noslip_iterations'] = int(getattr(simulation_options, 'noslip_iterations', 0))        # mjcf.py:1392-1397
         b.options['noslip_tolerance'] = float(getattr(simulation_options, 'noslip_tolerance', 1e-6))    # mjcf.py:1398-1403
+        b.options['integrator'] = str(getattr(simulation_options, 'integrator', 'Euler') or 'Euler')        # mjcf.py:1360-1365
 
     link_opts = {l.name: l for l in animat_options.morphology.links} if animat_options is not None else {}
     joint_opts = {j.name: j for j in animat_options.morphology.joints} if animat_options is not None else {}
@@ -313,7 +325,7 @@ def model2mjcf_xml(m: Model, fusestatic: bool = True) -> str:
     root = ET.Element('mujoco', model=str(getattr(m, 'name', 'animat')))
     ET.SubElement(root, 'compiler', angle='radian', eulerseq='xyz', inertiafromgeom='false', balanceinertia='false',
                   boundmass='0', boundinertia='0', fusestatic='true' if fusestatic else 'false')
-    ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator='Euler', cone={0: 'pyramidal', 1: 'elliptic'}[int(getattr(m, 'cone', 0))],
+    ET.SubElement(root, 'option', timestep=repr(float(m.timestep)), gravity=v(m.gravity), integrator={0: 'Euler', 1: 'RK4', 2: 'implicit', 3: 'implicitfast'}[int(getattr(m, 'integrator', 0))], cone={0: 'pyramidal', 1: 'elliptic'}[int(getattr(m, 'cone', 0))],
                   solver={0: 'PGS', 1: 'CG', 2: 'Newton'}[int(getattr(m, 'solver', 0))], iterations=str(int(m.solver_iterations)), tolerance=repr(float(m.solver_tolerance)),
                   ls_iterations=str(int(getattr(m, 'ls_iterations', 50))), ls_tolerance=repr(float(getattr(m, 'ls_tolerance', 0.01))),
                   impratio=repr(float(m.impratio)), noslip_iterations=str(int(getattr(m, 'noslip_iterations', 0))),

@@ -42,6 +42,13 @@ enum { FMJ_JNT_FREE = 0, FMJ_JNT_BALL = 1 /* unsupported */, FMJ_JNT_SLIDE = 2, 
  * simulation_options.solver / .cone to the option block, its own fallbacks being 'Newton' and 'pyramidal') */
 enum { FMJ_SOLVER_PGS = 0, FMJ_SOLVER_CG = 1, FMJ_SOLVER_NEWTON = 2 };
 enum { FMJ_CONE_PYRAMIDAL = 0, FMJ_CONE_ELLIPTIC = 1 };
+/* integrator (values follow MuJoCo's mjtIntegrator; reference mjcf.py:1360-1365 forwards simulation_options.integrator, its own fallback
+ * being 'Euler').  Implemented: Euler (with MuJoCo's implicit joint damping) and implicitfast.  For the models this path covers -
+ * joint-transmission actuators, joint spring-dampers, no fluid or tendon forces - the velocity derivative of the smooth forces that
+ * implicitfast keeps (passive + actuation, Coriolis terms dropped) is DIAGONAL: joint damping plus the velocity gain (-biasprm[2]) of
+ * every actuator whose force is not clamped by its forcerange, so implicitfast is the Euler step with that sum in place of the damping.
+ * RK4 (four forward passes per step) and implicit (the full, non-symmetric derivative incl. Coriolis terms, LU-factored) are refused. */
+enum { FMJ_INT_EULER = 0, FMJ_INT_RK4 = 1, FMJ_INT_IMPLICIT = 2, FMJ_INT_IMPLICITFAST = 3 };
 enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6, FMJ_GEOM_MESH = 7 };   /* mjtGeom values */
 
 /* per-env warning bits written to fmj_data.status (dm_control raises PhysicsError on these;
@@ -192,6 +199,9 @@ typedef struct fmj_model {
   int32_t noslip_iterations;    /* option.noslip_iterations (mjcf.py:1392-1397); 0 = off */
   double ls_tolerance;          /* option.ls_tolerance (default 0.01); <= 0: 0.01 */
   double noslip_tolerance;      /* option.noslip_tolerance (mjcf.py:1398-1403) */
+  /* ABI 5 */
+  int32_t integrator;           /* FMJ_INT_*: option.integrator (mjcf.py:1360-1365) */
+  int32_t reserved0;
 } fmj_model;
 
 /* ---- per-env device buffers for the physics step -------------------------------------------
@@ -315,8 +325,17 @@ int fmj_forward_debug(fmj_ctx* ctx, const fmj_data* d, int32_t disable_actuation
  * rows of an env is (limited sides active) + 4 * ncon - and, if pgs_improvement != NULL [n_envs, solver_iterations] DEVICE,
  * the decrease of the dual cost achieved by every PGS sweep that ran (never negative for a correct sweep; entries of sweeps
  * that did not run are left untouched).  maxefc / solver_iterations: fmj_constraint_info.  Not on the product path. */
+/* Under Newton / CG with the ELLIPTIC cone only slots 2 (R), 3, 4 (force), 6 (kind | id) and 7 (mu) of a contact's rows are meaningful:
+ * the solver keeps the contact's 3 x 3 Hessian block in slots 0 / 1 and the cone exchange in slot 5 (fmj_newton.inc); under Newton /
+ * CG in general slot 3 holds J qacc_smooth - aref. */
 int fmj_step_debug(fmj_ctx* ctx, const fmj_data* d, float* efc_rows, float* pgs_improvement, void* hip_stream);
 int fmj_constraint_info(const fmj_ctx* ctx, int32_t* maxefc, int32_t* max_contacts, int32_t* solver_iterations);
+/* The solver that actually runs (ABI 5).  fmj_create replaces a requested Newton / CG by the dual solver (PGS run to the solver's
+ * tolerance, up to 10 x solver_iterations sweeps: the same convex problem, the same minimiser) when some ground contact's friction
+ * after impratio is below 1e-3 - rows an fp32 primal iteration cannot resolve (the reference's arena has friction 0, mjcf.py:1202) -;
+ * *requested / *effective receive FMJ_SOLVER_* values, *iterations the sweep / iteration budget in force (fmj_step_debug's
+ * pgs_improvement rows are per sweep of the EFFECTIVE solver).  Any pointer may be NULL. */
+int fmj_solver_info(const fmj_ctx* ctx, int32_t* requested, int32_t* effective, int32_t* iterations);
 
 /* SwimmingHandler.step(iteration) (reference drag.pyx:389-411 -> drag_forces :152-268) for
  * every env: reads rows->links, writes rows->xfrc (rows of links above the surface are left

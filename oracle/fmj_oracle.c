@@ -1254,17 +1254,31 @@ static int forward(const fmj_model* m, ws_t* w, const double* qpos, const double
 static void euler(const fmj_model* m, ws_t* w, double* qpos, double* qvel) {
   int nv = m->nv; double h = m->timestep;
   int damped = 0;
-  for (int i = 0; i < nv; i++) damped |= (m->dof_damping[i] > 0);
+  /* mj_Euler: implicit in the joint damping (eulerdamp).  mj_implicit with mjINT_IMPLICITFAST: M - h D with D = d(qfrc_passive +
+   * qfrc_actuator)/d qvel, Coriolis terms dropped and D symmetrised; with joint-transmission actuators and joint dampers only, D is
+   * diagonal: -damping - sum over the joint's actuators of (-biasprm[2]) (mjd_passive_vel, mjd_actuator_vel; an actuator whose force
+   * sits on its forcerange contributes nothing).  Recalled from MuJoCo's documentation like everything else here: parity unpinned. */
+  double* bd = (double*)calloc((size_t)(nv > 0 ? nv : 1), sizeof(double));
+  for (int i = 0; i < nv; i++) bd[i] = m->dof_damping[i];
+  if (m->integrator == FMJ_INT_IMPLICITFAST && !w->disable_actuation) {
+    for (int a = 0; a < m->nu; a++) {
+      const double f = w->actuator_force[a];
+      if (m->actuator_forcelimited[a] && (f <= m->actuator_forcerange[2 * a] || f >= m->actuator_forcerange[2 * a + 1])) continue;
+      bd[m->jnt_dofadr[m->actuator_jntid[a]]] += -m->actuator_bias[3 * a + 2];
+    }
+  }
+  for (int i = 0; i < nv; i++) damped |= (bd[i] != 0);
   double* qacc = w->tmpv;
   if (!damped) memcpy(qacc, w->qacc, nv * sizeof(double));
   else {
     memcpy(w->qH, w->qM, m->nM * sizeof(double));
-    for (int i = 0; i < nv; i++) w->qH[m->dof_Madr[i]] += h * m->dof_damping[i];
+    for (int i = 0; i < nv; i++) w->qH[m->dof_Madr[i]] += h * bd[i];
     if (g_fp32_storage) round_to_f32(w->qH, m->nM);
     factor(m, w->qH, w->qH, w->qHDiagInv);
     for (int i = 0; i < nv; i++) qacc[i] = w->qfrc_smooth[i] + w->qfrc_constraint[i];
     solve_ld(m, qacc, w->qH, w->qHDiagInv);
   }
+  free(bd);
   for (int i = 0; i < nv; i++) qvel[i] += h * qacc[i];
   for (int j = 0; j < m->njnt; j++) {
     int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];

@@ -361,6 +361,17 @@ def test_root_position_past_the_limit_mid_launch_is_not_committed(maker):
     assert st[1] & 7 and not st[[0, 2, 3]].any()
     assert float(d.qpos[1, 0].abs()) <= 1e10 and torch.isfinite(d.qpos).all()
     assert float(d.time[1]) < T*m.timestep - 1e-6 and abs(float(d.time[0]) - T*m.timestep) < 1e-5
+    # ... and what it keeps is exactly the state after its last completed step: qpos, qvel AND time of step k, nothing of step k + 1
+    # (round 4: the root position is tested before anything of the step is committed)
+    k = int(round(float(d.time[1])/m.timestep))
+    assert 0 < k < T
+    phys2 = BatchedPhysics(m, n)
+    d2 = phys2.data
+    d2.qpos[:] = torch.as_tensor(qpos, dtype=torch.float32); d2.qvel[:] = torch.as_tensor(qvel, dtype=torch.float32)
+    phys2.step(k)
+    torch.cuda.synchronize()
+    assert int(d2.status[1]) == 0
+    assert torch.equal(d.qpos[1], d2.qpos[1]) and torch.equal(d.qvel[1], d2.qvel[1])
 
 
 # ---- ADVICE: links / xfrc subsets ----------------------------------------------------------------------------------------

@@ -11,7 +11,7 @@ def _relerr(a, b):
 
 
 def _make_sim(n_envs, n_iterations, buffer_size=None, units=None, water_kwargs=None, seed=0, env_offset=0, substeps=1,
-              swim_substep=None):
+              swim_substep=None, model_hook=None):
     import torch
     from farms_mujoco_amd.model import salamander33, synthetic_batch
     from farms_mujoco_amd.options import SimulationOptions, ArenaOptions, AnimatOptions, WaterOptions
@@ -19,6 +19,8 @@ def _make_sim(n_envs, n_iterations, buffer_size=None, units=None, water_kwargs=N
     from farms_mujoco_amd.simulation.simulation import Simulation
     from farms_mujoco_amd.units import SimulationUnitScaling
     m = salamander33(timestep=1e-3/substeps)       # the model steps at timestep / num_sub_steps (reference mjcf.py:1187-1192)
+    if model_hook is not None:
+        model_hook(m)
     qpos, qvel, psi = synthetic_batch(m, n_envs, seed=seed, env_offset=env_offset)
     opts = SimulationOptions(timestep=1e-3, n_iterations=n_iterations, units=units or SimulationUnitScaling(), num_sub_steps=substeps)
     arena = ArenaOptions(water=WaterOptions(**(water_kwargs or {})))

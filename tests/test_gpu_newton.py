@@ -466,7 +466,9 @@ def test_frictionless_contacts_under_the_primal_solvers(oracle, solver):
     qpos = np.tile(m.qpos0, (n, 1)); qpos[:, 7:] += rng.uniform(-0.1, 0.1, (n, m.nq - 7))
     qpos[:3, 2] = 0.015; qpos[:, 7 + 3] = 1.25
     qvel = rng.normal(size=(n, m.nv))*0.05; qvel[:, :2] += 0.2
-    phys = BatchedPhysics(m, n)
+    with pytest.warns(UserWarning, match='solved on the dual problem'):      # the swap is visible to the caller (fmj_solver_info, round 4)
+        phys = BatchedPhysics(m, n)
+    assert phys.solver_requested == {'newton': 'Newton', 'cg': 'CG'}[solver] and phys.solver_effective == 'PGS' and phys.solver_budget == 1000
     q32, v32, w32 = _set(phys, qpos, qvel)
     phys.step(1)
     torch.cuda.synchronize()

@@ -175,9 +175,12 @@ def test_unsupported_solver_options_are_refused():
     check_supported_options(SimulationOptions(solver='Newton'))        # round 3: the device has MuJoCo's Newton and CG solvers too
     check_supported_options(SimulationOptions(solver='CG'))
     check_supported_options(SimulationOptions(solver='Newton', cone='elliptic'))
+    check_supported_options(SimulationOptions(integrator='implicitfast'))     # round 4
+    check_supported_options(SimulationOptions(noslip_iterations=3), compile_only=True)      # the model compiler forwards it (MJCF export)
     check_supported_options(None)
-    for kw in (dict(cone='elliptic'), dict(cone='elliptic', solver='PGS'), dict(integrator='RK4'), dict(integrator='implicit'), dict(solver='SOR')):
-        with pytest.raises(NotImplementedError):
+    for kw, word in ((dict(cone='elliptic'), 'QCQP'), (dict(cone='elliptic', solver='PGS'), 'QCQP'), (dict(integrator='RK4'), 'four forward passes'),
+                     (dict(integrator='implicit'), 'Coriolis'), (dict(solver='SOR'), 'pgs'), (dict(noslip_iterations=3), 'noslip')):
+        with pytest.raises(NotImplementedError, match=word):      # a refusal says why
             check_supported_options(SimulationOptions(**kw))
 
 

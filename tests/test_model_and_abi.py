@@ -161,4 +161,13 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     m = salamander33(contacts=True, limits=True)
     m.cone = 1
     rc, msg = create(m)
-    assert rc == 2 and 'pyramidal' in msg, (rc, msg)
+    assert rc == 2 and 'QCQP' in msg and 'Newton or CG' in msg, (rc, msg)
+    m = salamander33()
+    for integ, ok in ((0, True), (3, True), (1, False), (2, False), (9, False)):     # Euler, implicitfast | RK4, implicit, junk
+        m.integrator = integ
+        rc, msg = create(m)
+        assert (rc in (0, 4)) if ok else (rc == 2 and 'FMJ_INT_IMPLICITFAST' in msg and 'RK4' in msg), (integ, rc, msg)
+    m = salamander33(contacts=True, limits=True)
+    m.noslip_iterations = 3
+    rc, msg = create(m)
+    assert rc == 2 and 'noslip' in msg and 'not implemented' in msg, (rc, msg)

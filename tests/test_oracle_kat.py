@@ -332,3 +332,44 @@ def test_sinking_link_terminal_velocity(oracle):
     buoy = 1000.0*9.81*mass/density                      # fully submerged
     vt = np.sqrt((mass*9.81 - buoy)/cz)
     assert abs(-o['qvel'][0, 2] - vt) < 1e-3*vt, (o['qvel'][0, 2], vt)
+
+
+def _servo_hinge(integrator, h=2e-3, B=0.05, kv=0.4, kp=0.0, forcerange=None):
+    b = ModelBuilder('servo', timestep=h, gravity=(0, 0, 0))
+    b.options['integrator'] = integrator
+    b.add_body('l', 'world', mass=0.5, ipos=(0.1, 0, 0), inertia=(1e-3, 2e-3, 3e-3), joint='hinge', jname='j', axis=(0, 0, 1), damping=B)
+    b.add_joint_actuators('j', kp=kp, kv=kv, forcerange=forcerange)
+    return b.compile(), 3e-3 + 0.5*0.1**2
+
+
+def test_implicitfast_velocity_servo_recurrence(oracle):
+    """implicitfast (MuJoCo mj_implicit with the Coriolis derivatives dropped): (I + h(B + kv)) (w+ - w) = h (kv (c - w) - B w), i.e. the
+    velocity gain of the actuator joins the joint damping on the implicit side.  Euler keeps the actuator explicit: only B is implicit."""
+    h, B, kv, c, w0 = 2e-3, 0.05, 0.4, 1.5, -0.7
+    for integ in ('implicitfast', 'Euler'):
+        m, I = _servo_hinge(integ, h, B, kv)
+        assert m.integrator == (3 if integ == 'implicitfast' else 0)
+        o = oracle.step(m, np.zeros((1, 1)), np.array([[w0]]), ctrl=np.array([[0.0, c, 0.0]]), n_steps=40)
+        w = w0
+        for _ in range(40):
+            w += h*(kv*(c - w) - B*w)/(I + h*(B + (kv if integ == 'implicitfast' else 0.0)))
+        assert abs(o['qvel'][0, 0] - w) < 1e-13, integ
+
+
+def test_implicitfast_skips_a_clamped_actuator(oracle):
+    """mjd_actuator_vel: an actuator whose force sits on its forcerange has no velocity derivative, so a saturated servo steps exactly
+    like Euler; the derivative comes back once the force leaves the limit."""
+    h, B, kv, c = 2e-3, 0.05, 0.4, 5.0
+    fr = (-0.2, 0.2)                                     # kv (c - w) = 2.0 at w = 0: saturated until w > c - 0.5
+    out = {}
+    for integ in ('implicitfast', 'Euler'):
+        m, I = _servo_hinge(integ, h, B, kv, forcerange=fr)
+        out[integ] = oracle.step(m, np.zeros((1, 1)), np.zeros((1, 1)), ctrl=np.array([[0.0, c, 0.0]]), n_steps=25)['qvel'][0, 0]
+    w = 0.0
+    for _ in range(25):
+        w += h*(0.2 - B*w)/(I + h*B)
+    assert abs(out['Euler'] - w) < 1e-13 and out['implicitfast'] == out['Euler']
+    m, I = _servo_hinge('implicitfast', h, B, kv, forcerange=fr)
+    w0 = c - 0.1                                          # force = 0.04: inside the range
+    o = oracle.step(m, np.zeros((1, 1)), np.array([[w0]]), ctrl=np.array([[0.0, c, 0.0]]), n_steps=1)
+    assert abs(o['qvel'][0, 0] - (w0 + h*(kv*(c - w0) - B*w0)/(I + h*(B + kv)))) < 1e-14
