@@ -1108,11 +1108,10 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       const float4 dp = DTAB(dlo, 1);
       if (isd && dp.w != 0.f && di.w >= 0) {
         const int index = it % A.buffer_size;
-        float* row = glob(A.joints) + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
-        row[FMJ_JOINT_POSITION] = QP[__float_as_int(dp.z)];
-        row[FMJ_JOINT_VELOCITY] = QV[lane] * A.inv_angvel;
-        row[FMJ_JOINT_TORQUE] = cy_actsum;
-        row[FMJ_JOINT_LIMIT_FORCE] = cy_limfrc;
+        float AS1* row = gptr(A.joints) + ((size_t)index * A.row_stride_joints + (size_t)env * M.n_joints * FMJ_JOINT_SIZE) + di.w * FMJ_JOINT_SIZE;
+        stg4(row + 0, QP[__float_as_int(dp.z)], QV[lane] * A.inv_angvel, 0.f, 0.f);      // the whole row, as in fmj_dual2.inc
+        stg4(row + 4, 0.f, 0.f, 0.f, 0.f);
+        stg4(row + 8, cy_actsum, cy_limfrc, 0.f, 0.f);
       }
     }
 
@@ -1804,6 +1803,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
 
 #undef M
 #undef A
+static_assert(FMJ_JOINT_POSITION == 0 && FMJ_JOINT_VELOCITY == 1 && FMJ_JOINT_TORQUE == 8 && FMJ_JOINT_LIMIT_FORCE == 9 && FMJ_JOINT_SIZE == 12, "the fused kernels store a joints row as three float4");
 #include "fmj_dual2.inc"
 #include "fmj_cons2.inc"
 

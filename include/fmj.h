@@ -74,7 +74,7 @@ enum {
   FMJ_LINK_SIZE = 20,
   FMJ_JOINT_POSITION = 0,
   FMJ_JOINT_VELOCITY = 1,
-  FMJ_JOINT_FORCE = 2,     /* 3 (force sensors, unused unless use_frc_trq_sensors) */
+  FMJ_JOINT_FORCE = 2,     /* 3 (force sensors, unused unless use_frc_trq_sensors: fmj_step_fused stores 0 in columns 2..7 and 10..11) */
   FMJ_JOINT_TORQUE3 = 5,   /* 3 */
   FMJ_JOINT_TORQUE = 8,    /* motor torque = sum of the 3 actuatorfrc (physics.py:510-524) */
   FMJ_JOINT_LIMIT_FORCE = 9,
