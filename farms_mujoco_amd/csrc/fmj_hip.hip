@@ -2503,7 +2503,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
         }
       }
       D.dual_nround = (int)rounds.size();
-      if (rounds.empty()) { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; rounds.push_back(R); }
+      { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; R.depth = -1; rounds.push_back(R); }     // terminator: the two-env kernel's loops stop at it and read it as 'the round after the last'
       UP(rounds, dual_rounds);
       {   // per lane dof, per absolute depth: byte = 4 * lane of the ancestor at that depth (the solve pulls x from there
           // with ds_bpermute); own lane where there is none.  The kernel adds the half's offset.
