@@ -53,7 +53,8 @@ struct DualRound {
   int p0, p1, p2, depth;              // lane dofs, their absolute depth; p1 = -1: single-member round; an absent third
                                       // member repeats p0 under empty masks
   unsigned long long anc[3];          // lanes whose dof is a proper ancestor of p_c
-  unsigned long long desc[3];         // lanes whose dof is a proper descendant of p_c
+  int ro[3];                          // two-env kernel: byte offset of p_c's published row, p_c * dual_row_stride(rs) * 4; ro[1] = -1 in a single-member round
+  int pad_[3];
 };
 
 // The same for ldl_factor of the one-env kernel: up to SIX dofs of a level per round (a centipede has five per level: one round
@@ -2439,7 +2440,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
           int* pp[3] = {&R.p0, &R.p1, &R.p2};
           R.depth = dep;
           for (int c = 0; c < 3; c++) {
-            if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; R.desc[c] = descm[pv]; }
+            if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; }
             else *pp[c] = c == 1 ? -1 : R.p0;
           }
           rounds.push_back(R);
@@ -2495,15 +2496,16 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
             int* pp[3] = {&R.p0, &R.p1, &R.p2};
             R.depth = dep;
             for (int c = 0; c < 3; c++) {
-              if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; R.desc[c] = descm[pv]; }
+              if (q + c < lvl.size()) { const int pv = lvl[q + c]; *pp[c] = pv; R.anc[c] = ancm[pv]; }
               else *pp[c] = c == 1 ? -1 : R.p0;
             }
+            for (int c = 0; c < 3; c++) R.ro[c] = *pp[c] < 0 ? -1 : *pp[c] * dual_row_stride(D.rs) * 4;
             rounds.push_back(R);
           }
         }
       }
       D.dual_nround = (int)rounds.size();
-      { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; R.depth = -1; rounds.push_back(R); }     // terminator: the two-env kernel's loops stop at it and read it as 'the round after the last'
+      { DualRound R; memset(&R, 0, sizeof R); R.p1 = -1; R.ro[1] = -1; R.depth = -1; rounds.push_back(R); }     // terminator: the two-env kernel's loops stop at it and read it as 'the round after the last'
       UP(rounds, dual_rounds);
       {   // per lane dof, per absolute depth: byte = 4 * lane of the ancestor at that depth (the solve pulls x from there
           // with ds_bpermute); own lane where there is none.  The kernel adds the half's offset.
