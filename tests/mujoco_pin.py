@@ -25,6 +25,17 @@ def _salamander(**kw):
     return m
 
 
+def _servo_salamander(integrator, kv=2e-3, **kw):
+    """Velocity servos with a gain (the zoo's own kv is 0, where implicitfast and Euler coincide) and the integrator under test."""
+    import farms_mujoco_amd.model as mm
+    m = _salamander(**kw)
+    for a, tag in enumerate(m.actuator_tags):
+        if tag == 'velocity':
+            m.actuator_gain[a] = kv; m.actuator_bias[a, 2] = -kv
+    m.integrator = mm.INTEGRATORS[integrator]
+    return m
+
+
 def _tree(seed, **kw):
     from test_gpu_random_trees import random_tree
     return random_tree(seed, **kw)
@@ -47,6 +58,8 @@ CASES = {
     'salamander33_walk_pairs': (lambda: _salamander(contacts=True, limits=True, spawn_z=0.045, self_collisions=True), True),
     'salamander33_walk_hfield': (lambda: _salamander(contacts=True, limits=True, spawn_z=0.045, terrain='hfield'), False),
     'salamander33_walk_mesh': (lambda: _salamander(contacts=True, limits=True, spawn_z=0.045, mesh_feet=True), False),
+    'salamander33_swim_implicitfast': (lambda: _servo_salamander('implicitfast'), True),
+    'salamander33_walk_implicitfast': (lambda: _servo_salamander('implicitfast', contacts=True, limits=True, spawn_z=0.045), True),
     'eel': (lambda: _morph('eel'), True),
     'centipede': (lambda: _morph('centipede'), True),
     'tree_0': (lambda: _tree(0), True), 'tree_1': (lambda: _tree(1), True), 'tree_2': (lambda: _tree(2), True),
