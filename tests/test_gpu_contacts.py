@@ -924,3 +924,65 @@ def test_thousand_steps_of_walking(oracle, solver):
     # an env that left the oracle's walk did so through an event, not through drift: it is either on it (1e-4) or far from it
     r = stats[1000][0]
     assert ((r <= 1e-4) | (r > 5e-4)).mean() > 0.8
+
+
+@pytest.mark.parametrize('dual', ['1', '0'], ids=['two_per_wave', 'one_per_wave'])
+@pytest.mark.parametrize('substeps', [2, 3])
+def test_fused_walk_with_substeps(oracle, monkeypatch, substeps, dual):
+    """Walking with num_sub_steps > 1 (reference task.py:168-186,348-369: joint and contact rows once per iteration, at the full
+    step; the model steps at timestep / S) through both constraint kernels: the fused launch equals the operator-by-operator path row
+    for row, and both follow the oracle's restatement of the task's counters."""
+    import os
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.model import salamander33
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    monkeypatch.setenv('FMJ_DUAL', dual)
+    S, h = substeps, 1e-3
+    m = salamander33(contacts=True, limits=True, spawn_z=0.045, timestep=h/S)
+    n, T = 6, 30
+    pairs = [(b, '') for b in m.body_names[1:] if b.endswith('_3')] + [('world', 'body_0'), ('world', '')]
+    rng = np.random.default_rng(21)
+    q0 = np.tile(m.key_qpos, (n, 1)); q0[:, 7:] += rng.uniform(-0.15, 0.15, (n, m.nq - 7)); q0[:, 2] = 0.03 + 0.01*rng.uniform(size=n)
+
+    def make():
+        data = AnimatData(h, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+        sim = Simulation(m, m.body_names[1], SimulationOptions(timestep=h, n_iterations=T, num_sub_steps=S), n_envs=n, data=data, buffer_size=T)
+        sim.reset()
+        sim.physics.data.qpos[:] = torch.as_tensor(q0, dtype=torch.float32)
+        sim.physics.forward(disable_actuation=True)
+        return sim, data
+    sim_f, data_f = make()
+    sim_u, data_u = make()
+    assert sim_f.physics.kernel_info()['threads_per_env'] == (32 if dual == '1' else 64)
+    d = sim_f.physics.data
+    q32 = d.qpos.cpu().numpy().astype(np.float64); v32 = d.qvel.cpu().numpy().astype(np.float64)
+    st = dict(qpos=q32, qvel=v32)
+    fds = [oracle.forward_debug(m, q32[e], v32[e]) for e in range(n)]
+    for k in ('xpos', 'xquat', 'xipos'):
+        st[k] = np.array([fd[k] for fd in fds])
+    sd = np.array([fd['sensordata'] for fd in fds]); sd[:, 6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0
+    st['sensordata'] = sd
+    assert sim_f.task.fusable()
+    sim_f.run(fused=True, chunk=7)                          # launch boundaries inside and between iterations' sub-steps
+    sim_u.run(fused=False)
+    torch.cuda.synchronize()
+    assert int(d.status.abs().sum()) == 0
+    for k in ('links', 'contacts'):
+        a = getattr(data_f.sensors, k).array.cpu().numpy(); b = getattr(data_u.sensors, k).array.cpu().numpy()
+        assert np.array_equal(a, b), k
+    ja = data_f.sensors.joints.array.cpu().numpy(); jb = data_u.sensors.joints.array.cpu().numpy()
+    assert np.allclose(ja, jb, rtol=1e-5, atol=2e-7)       # (the row at a launch boundary: see test_fused_substeps_chunked_equals_one_launch)
+    assert np.array_equal(sim_f.physics.data.qpos.cpu().numpy(), sim_u.physics.data.qpos.cpu().numpy())
+    g2d = sim_f.task.maps['sensors']['geompair2data']
+    ref = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                           n_contact_rows=len(pairs), n_threads=8, substeps=S)
+    rows = data_f.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
+    scale = np.abs(want[..., :9]).max()
+    err_f = np.abs(rows[..., :9] - want[..., :9]).max()/scale
+    print('substeps', S, 'contact rows force rel err', err_f, 'peak', scale, 'qpos', _relerr(d.qpos.cpu().numpy(), ref['qpos']))
+    assert err_f < 2e-3 and scale > 0.05
+    assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3
+    assert _relerr(data_f.sensors.links.array.cpu().numpy(), ref['links']) < 2e-3
+    assert _relerr(ja[..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]]) < 2e-2
