@@ -13,7 +13,10 @@ pytestmark = pytest.mark.gpu
 def _servo_model(maker, integrator, kv=2e-3, clamp=False, **kw):
     """A zoo model whose velocity actuators have a gain (the zoo's own kv is 0, where implicitfast and Euler coincide)."""
     import farms_mujoco_amd.model as mm
+    kw = dict(kw); solver = kw.pop('solver', None)
     m = getattr(mm, maker)(**kw)
+    if solver:
+        m.solver = mm.SOLVERS[solver]; m.solver_iterations = 100
     for a, tag in enumerate(m.actuator_tags):
         if tag == 'velocity':
             m.actuator_gain[a] = kv; m.actuator_bias[a, 2] = -kv
@@ -23,11 +26,11 @@ def _servo_model(maker, integrator, kv=2e-3, clamp=False, **kw):
     return m
 
 
-def _state(m, n, seed):
+def _state(m, n, seed, vscale=0.3):
     import farms_mujoco_amd.model as mm
     rng = np.random.default_rng(seed)
     qpos, qvel, _ = mm.synthetic_batch(m, n, seed=seed)
-    qvel = qvel + rng.normal(size=qvel.shape)*0.3
+    qvel = qvel + rng.normal(size=qvel.shape)*vscale
     ctrl = np.zeros((n, m.nu))
     for a, tag in enumerate(m.actuator_tags):
         if tag == 'position':
@@ -53,8 +56,9 @@ def _run(m, qpos, qvel, ctrl, n_steps):
 
 
 @pytest.mark.parametrize('clamp', [False, True])
-@pytest.mark.parametrize('kw,dual', [({}, '1'), ({}, '0'), (dict(contacts=True, limits=True), '1'), (dict(contacts=True, limits=True), '0')],
-                         ids=['two_per_wave', 'one_per_wave', 'two_per_wave_constrained', 'one_per_wave_constrained'])
+@pytest.mark.parametrize('kw,dual', [({}, '1'), ({}, '0'), (dict(contacts=True, limits=True, spawn_z=0.045), '1'), (dict(contacts=True, limits=True, spawn_z=0.045), '0'),
+                                     (dict(contacts=True, limits=True, spawn_z=0.045, solver='newton'), '0')],
+                         ids=['two_per_wave', 'one_per_wave', 'two_per_wave_constrained', 'one_per_wave_constrained', 'one_per_wave_newton'])
 def test_implicitfast_step_matches_oracle(oracle, monkeypatch, kw, dual, clamp):
     """One step and 200 steps from random states with random velocity-servo targets.  qvel is held to the same fp32-storage floor as
     the Euler step (tests/test_gpu_step_parity.py), and the test has teeth: the Euler result of the same inputs is further from the
@@ -62,7 +66,9 @@ def test_implicitfast_step_matches_oracle(oracle, monkeypatch, kw, dual, clamp):
     n, maker, tpe = 32, 'salamander33', 32 if dual == '1' else 64
     monkeypatch.setenv('FMJ_DUAL', dual)                 # '0': the one-env kernels step the same model
     m = _servo_model(maker, 'implicitfast', clamp=clamp, **kw)
-    qpos, qvel, ctrl = _state(m, n, 11)
+    # (the primal solvers are held to states of walking speed, as in tests/test_gpu_newton.py: from the violent ones an fp32 Newton
+    # iteration and the fp64 one stop at different iterates - 4 % of qvel, under Euler as under implicitfast)
+    qpos, qvel, ctrl = _state(m, n, 11, vscale=0.02 if kw.get('solver') else 0.3)
     phys, (q32, v32, c32), q1, v1 = _run(m, qpos, qvel, ctrl, 1)
     assert phys.kernel_info()['threads_per_env'] == tpe
     ref = oracle.step(m, q32, v32, ctrl=c32)
