@@ -139,7 +139,7 @@ def cpu_baseline(m, sim, target_seconds=12.0):
     n_steps = int(max(50, min(20000, target_seconds*rate/n_envs)))
     t0 = time.perf_counter()
     oracle.run_fused(m, st, n_steps, swim=h.swim_dict(), water=water, buffer_size=100, controller=1, wave=wave,
-                     n_threads=cores)                                          # rows go to a 100-row ring, like the GPU run
+                     n_threads=cores)                                          # rows go to a 100-row ring (the ring length does not change what the oracle computes)
     dt = time.perf_counter() - t0
     out = dict(value=n_envs*n_steps/dt, unit='env-steps/s', cores=cores, kind='port',
                sample=f'{n_envs} envs x {n_steps} steps of the same salamander-33 swim workload, fp64 C oracle '
@@ -174,23 +174,24 @@ def mujoco_baseline(m, qpos, qvel, target_seconds=5.0):
 
 def other_workloads(n_envs, chunk, device):
     """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS; and with the Newton solver) and configs[4] (eel + centipede buckets) on
-    this GPU: env-steps/s over 500 timed steps after a warm-up (walking: 1000 steps, so that the animals stand and walk)."""
+    this GPU: env-steps/s over 1000 timed steps (at least one launch) after a warm-up of 1000 (the animals stand and walk by then)."""
     import torch
     from farms_mujoco_amd.simulation.buckets import BucketedSimulation
     res = {}
-    for name, warm, steps in (('walk', 1000, 500), ('walk_newton', 1000, 500), ('mixed', 300, 500)):
+    for name, warm, steps in (('walk', 1000, 1000), ('walk_newton', 1000, 1000), ('mixed', 1000, 1000)):
         if name == 'mixed':
             sims = [build_sim(n_envs//2, 1 << 30, chunk, 0, device, morphology='eel')[0],
                     build_sim(n_envs - n_envs//2, 1 << 30, chunk, n_envs//2, device, morphology='centipede')[0]]
         else:
             sims = [build_sim(n_envs, 1 << 30, chunk, 0, device, workload=name)[0]]
         batch = BucketedSimulation(sims)
-        for _ in range(warm//chunk):
+        nl = max(1, steps//chunk)                           # timed launches of `chunk` steps
+        for _ in range(max(1, warm//chunk)):
             batch.step_fused(chunk)
         torch.cuda.synchronize()
         evs = []
         t0 = time.perf_counter()
-        for _ in range(steps//chunk):
+        for _ in range(nl):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             batch.step_fused(chunk)
@@ -201,7 +202,7 @@ def other_workloads(n_envs, chunk, device):
         for s_ in sims:
             s_.physics.check_invalid_state()
         ms = np.array([a.elapsed_time(b) for a, b in evs])
-        res[name] = {'value': n_envs*(steps//chunk)*chunk/dt, 'unit': 'env-steps/s', 'warmup': warm, 'steps': (steps//chunk)*chunk,
+        res[name] = {'value': n_envs*nl*chunk/dt, 'unit': 'env-steps/s', 'warmup': max(1, warm//chunk)*chunk, 'steps': nl*chunk, 'steps_per_launch': chunk,
                      'launch_ms': {'min': float(ms.min()), 'median': float(np.median(ms)), 'max': float(ms.max())},
                      'config': 'BASELINE configs[3]: salamander-33 walking on a plane' if name == 'walk' else
                                'configs[3] with MuJoCo\'s Newton solver (the reference\'s fallback, mjcf.py:1348-1359) instead of PGS x 50' if name == 'walk_newton' else
@@ -217,9 +218,9 @@ def api_paths(n_envs, chunk, device):
     launch per operator and physics step - what a run with host callbacks costs).  env-steps/s; an env-step = one mj_step of one env."""
     import torch
     out = {}
-    for name, n_it, sub, fused in (('run_fused', 3000, 1, True), ('run_fused_substeps2', 1500, 2, True), ('run_unfused', 300, 1, False)):
+    for name, n_it, sub, fused in (('run_fused', 4*chunk, 1, True), ('run_fused_substeps2', 3*chunk, 2, True), ('run_unfused', 300, 1, False)):
         sim, m, _ = build_sim(n_envs, n_it, chunk, 0, device, substeps=sub)
-        warm = 3*chunk if fused else 20
+        warm = chunk if fused else 20                          # (iterations; the ring holds `chunk` of them, a fused launch fills it once)
         sim.task.n_iterations = warm; sim.task.sim_iterations = warm*sub
         sim.run(fused=fused)                                   # warm-up through the same call
         sim.task.n_iterations = n_it; sim.task.sim_iterations = n_it*sub
@@ -255,7 +256,10 @@ def main():
     ap.add_argument('--steps', type=int, default=1000)
     ap.add_argument('--warmup', type=int, default=3000)
     ap.add_argument('--envs-per-gpu', type=int, default=4096)
-    ap.add_argument('--chunk', type=int, default=100, help='steps per fused launch (= ring-buffer length)')
+    ap.add_argument('--chunk', type=int, default=1000,
+                    help='steps per fused launch = ring-buffer length.  1000 = the reference logs a whole 1000-iteration run (AnimatData of n_iterations '
+                         'rows, task.py:62,158); 100 was the default up to round 4 and is what every same-box A/B of DESIGN.md used.  Longer launches '
+                         'amortise prologue / epilogue and - walking - average the uneven contact load of the waves of the one resident round')
     ap.add_argument('--min-seconds', type=float, default=2.0,
                     help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
     ap.add_argument('--no-cpu-baseline', action='store_true')

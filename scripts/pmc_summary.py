@@ -17,7 +17,7 @@ envs, steps = bench['config']['envs_per_gpu'], bench['config']['steps_per_launch
 b_alg = bench['roofline']['algorithmic_bytes_per_env_step']
 dual = 'two envs per wave' in bench['roofline']['kernel']
 waves = (envs + 1)//2 if dual else envs
-out = [head, f'source: scripts/profile.sh {tag} (rocprofv3 --pmc passes around: python bench.py --no-cpu-baseline --steps 500 --warmup 500 ...)',
+out = [head, f'source: scripts/profile.sh {tag} (rocprofv3 --pmc passes around: python bench.py --no-cpu-baseline --no-extras --steps 1000 --warmup 1000 ...)',
        f'bench line of the same build: {bench["value"]/1e6:.1f} M env-steps/s, launch {bench["launch_ms"]["median"]:.3f} ms (median of {bench["launch_ms"]["n"]})',
        f'full launches = {envs} envs x {steps} steps; algorithmic bytes/launch = {b_alg} B x {envs*steps} = {b_alg*envs*steps:.3e}', '']
 acc = collections.defaultdict(list)

@@ -6,7 +6,7 @@ set -e
 tag=$1; shift
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p $out
-args="--no-cpu-baseline --no-extras --steps ${STEPS:-500} --warmup ${WARMUP:-500} $@"
+args="--no-cpu-baseline --no-extras --steps ${STEPS:-1000} --warmup ${WARMUP:-1000} $@"
 export TMPDIR=/tmp
 python3 bench.py $args > $out/bench.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/trace -- python3 bench.py $args > /dev/null
