@@ -5,12 +5,13 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 50000
+L = int(os.environ.get('FMJ_SOAK_LAUNCH', '1000'))      # steps per launch (= ring length)
 workloads = [(w, 4096) for w in os.environ['FMJ_SOAK'].split(',')] if 'FMJ_SOAK' in os.environ else (('swim', 4096), ('walk', 4096), ('swim', 8191))
 for workload, n in workloads:
-    sim, m, _ = bench.build_sim(n, 1 << 30, 100, 0, 'cuda:0', workload)
+    sim, m, _ = bench.build_sim(n, 1 << 30, L, 0, 'cuda:0', workload)
     t0 = time.perf_counter()
-    for _ in range((steps if workload == 'swim' else steps//4)//100):
-        sim.step_fused(100)
+    for _ in range(max(1, (steps if workload == 'swim' else steps//4)//L)):
+        sim.step_fused(L)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     d = sim.physics.data
