@@ -174,11 +174,11 @@ def mujoco_baseline(m, qpos, qvel, target_seconds=5.0):
 
 def other_workloads(n_envs, chunk, device):
     """Short measurements of BASELINE configs[3] (walking: limits + contacts + PGS; and with the Newton solver) and configs[4] (eel + centipede buckets) on
-    this GPU: env-steps/s over 1000 timed steps (at least one launch) after a warm-up of 1000 (the animals stand and walk by then)."""
+    this GPU: env-steps/s over 3000 timed steps (at least one launch) after a warm-up of 1000 (the animals stand and walk by then)."""
     import torch
     from farms_mujoco_amd.simulation.buckets import BucketedSimulation
     res = {}
-    for name, warm, steps in (('walk', 1000, 1000), ('walk_newton', 1000, 1000), ('mixed', 1000, 1000)):
+    for name, warm, steps in (('walk', 1000, 3000), ('walk_newton', 1000, 3000), ('mixed', 1000, 3000)):
         if name == 'mixed':
             sims = [build_sim(n_envs//2, 1 << 30, chunk, 0, device, morphology='eel')[0],
                     build_sim(n_envs - n_envs//2, 1 << 30, chunk, n_envs//2, device, morphology='centipede')[0]]
