@@ -108,7 +108,7 @@ def build_id() -> str:
         if f.endswith('.hip') or f.endswith('.inc'):
             h.update(f.encode()); h.update(open(os.path.join(CSRC, f), 'rb').read())
     h.update(open(HEADER, 'rb').read())
-    return h.hexdigest()[:16]
+    return h.hexdigest()[:16] + ('-devlink' if os.path.exists(SO_PATH + '.devlink') else '')
 
 
 _lib = None
@@ -140,18 +140,39 @@ def build(force: bool = False, verbose: bool = False, defines=(), out: str = Non
             todo = jobs
 
         def cc(job):
+            # compiled under a per-process name, then renamed into place: two builds at once (two ranks, two pytest workers) never
+            # read each other's half-written objects
             obj, defs = job
-            cmd = ['hipcc'] + flags + defs + ['-c', src, '-o', obj]
+            tmp = f'{obj}.{os.getpid()}.tmp'
+            cmd = ['hipcc'] + flags + defs + ['-c', src, '-o', tmp]
             if verbose:
                 print(' '.join(cmd))
-            subprocess.check_call(cmd)
+            try:
+                subprocess.check_call(cmd)
+                os.replace(tmp, obj)
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
             return obj
         with concurrent.futures.ThreadPoolExecutor(max_workers=min(len(todo), os.cpu_count() or 1)) as ex:
             list(ex.map(cc, todo))
-        cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[0] for j in jobs] + ['-o', target]
+        tmp_target = f'{target}.{os.getpid()}.tmp'
+        cmd = ['hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + [j[0] for j in jobs] + ['-o', tmp_target]
         if verbose:
             print(' '.join(cmd))
-        subprocess.check_call(cmd)
+        try:
+            subprocess.check_call(cmd)
+            os.replace(tmp_target, target)
+        finally:
+            if os.path.exists(tmp_target):
+                os.remove(tmp_target)
+        # a development link (FMJ_DEV_MAXD) may hold stale objects: it leaves a marker next to the library that build_id() reports,
+        # so a measurement taken on it cannot pass for one of a clean build; a full build removes the marker
+        marker = target + '.devlink'
+        if dev:
+            open(marker, 'w').write(','.join(map(str, dev)))
+        elif os.path.exists(marker):
+            os.remove(marker)
     return target
 
 

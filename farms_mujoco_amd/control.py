@@ -166,6 +166,7 @@ class NetworkController(AnimatController):
         # the network advances once per ITERATION (task.py:288-346 calls the controller on full steps only): with sub-steps pass
         # simulation_options.timestep, the model's own timestep being timestep / num_sub_steps (mjcf.py:1187-1192)
         self.timestep = float(model.timestep if timestep is None else timestep)
+        self._timestep_given = timestep is not None      # ExperimentTask.initialize_control sets / validates it against task.timestep
         self._lib = _lib.load()
         import ctypes
         self._ctx = ctypes.c_void_p()
@@ -193,6 +194,15 @@ class NetworkController(AnimatController):
                 self._ctx = None
         except Exception:
             pass
+
+    def state_dict(self):
+        """Oscillator state for Simulation.save_state (phases, amplitudes and their rates, per env)."""
+        return {k: getattr(self, k).detach().cpu().numpy().copy() for k in ('phase', 'amp', 'damp')}
+
+    def load_state_dict(self, state):
+        for k in ('phase', 'amp', 'damp'):
+            t = getattr(self, k)
+            t.copy_(torch.as_tensor(np.asarray(state[k]), dtype=t.dtype))
 
     def ctrl_tape(self, n_steps):
         """Advance the network ``n_steps`` and return ctrl[n_steps, n_envs, nu] (device)."""

@@ -136,6 +136,24 @@ class BatchedPhysics:
         _lib.check(self._lib.fmj_step_debug(self._ctx, ctypes.byref(c), _ptr(rows), _ptr(imp), _stream_ptr(self.device)))
         return rows, imp
 
+    # ---- checkpoint / resume ---------------------------------------------------------
+    STATE_FIELDS = ('qpos', 'qvel', 'ctrl', 'qpos_spring', 'xfrc_applied', 'xpos', 'xquat', 'xipos', 'sensordata', 'qacc',
+                    'time', 'status', 'qacc_warmstart', 'contact', 'ncon')
+
+    def get_state(self):
+        """Every mjData field as a host array: the integrated state (qpos, qvel, qpos_spring, time, status), the solver's warm
+        start, and the derived fields of the last step (poses, sensordata, contacts) that the NEXT step's row readout reports
+        (mj_step lag).  ``set_state`` of this dict on a context of the same model and batch resumes bitwise."""
+        return {k: getattr(self.data, k).detach().cpu().numpy().copy() for k in self.STATE_FIELDS}
+
+    def set_state(self, state):
+        for k in self.STATE_FIELDS:
+            t = getattr(self.data, k)
+            a = np.asarray(state[k])
+            if tuple(a.shape) != tuple(t.shape):
+                raise ValueError(f'state field {k}: shape {a.shape}, this context holds {tuple(t.shape)}')
+            t.copy_(torch.as_tensor(a, dtype=t.dtype))
+
     def check_invalid_state(self):
         """Raise PhysicsError if any env reported a bad-state warning (lazy, one sync)."""
         bad = torch.nonzero(self.data.status).flatten()

@@ -36,36 +36,40 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     sensor_maps['datalinks2xfrc'] = links_body
     sensor_maps['data2xfrc'] = np.array([m.body_names.index(n) for n in sensor_data.xfrc.names], np.int32)
     physics.set_readout_maps(links_body, joints_jnt)
-    # Contacts (reference physics.py:360-382): a sensor named (body, '') takes every geom of that body as key
-    # (geom, -1); a sensor named (body1, body2) takes every ordered geom pair (geom of body1, geom of body2)
-    contacts_pairs = list(sensor_data.contacts.names)
-    body_names = m.body_names
-    geompair2data = {
-        (geom_id, -1): contacts_pairs.index((body_names[body_id], ''))
-        for geom_id, body_id in enumerate(m.geom_bodyid[:m.ngeom])
-        if (body_names[body_id], '') in contacts_pairs
-    }
-    if any(pair[1] != '' for pair in contacts_pairs if not isinstance(pair, str) and len(pair) == 2):
-        geompair2data.update({
-            (geom_id1, geom_id2): contacts_pairs.index((body_names[body_id1], body_names[body_id2]))
-            for geom_id1, body_id1 in enumerate(m.geom_bodyid[:m.ngeom])
-            for geom_id2, body_id2 in enumerate(m.geom_bodyid[:m.ngeom])
-            if (body_names[body_id1], body_names[body_id2]) in contacts_pairs
-        })
+    # Contact sensors.  Contract of reference physics.py:360-382: ``geompair2data`` maps (geom, -1) to the row of the sensor named
+    # (body of geom, '') and (geom1, geom2) to the row of the sensor named (body1, body2), every geom of a body counting for its body.
+    # Built from a body -> geoms table: a sensor row fans out to its body's geoms (or the product of two bodies' geoms).
+    sensor_names = list(sensor_data.contacts.names)
+    for name in sensor_names:
+        if isinstance(name, str) or len(name) != 2:
+            raise ValueError(f'contact sensor {name!r}: expected a (body, body-or-empty) pair of strings')
+    body_index = {name: b for b, name in enumerate(m.body_names)}
+    geom_body = np.asarray(m.geom_bodyid[:m.ngeom], np.int64)
+    geoms_of = {b: np.nonzero(geom_body == b)[0] for b in np.unique(geom_body)}
+    geompair2data = {}
+    geom_sensor = np.full(max(m.ngeom, 1), -1, np.int32)
+    pair_rows = []
+    if len(set(map(tuple, sensor_names))) != len(sensor_names):      # the reference's "Missing pair" assertion fires on a repeated name too
+        raise ValueError(f'contact sensor names must be unique: {sensor_names}')
+    for row, (first, second) in enumerate(sensor_names):
+        g1 = geoms_of.get(body_index.get(first, -1), ())
+        if second == '':
+            for g in g1:
+                geompair2data[(int(g), -1)] = row
+                geom_sensor[g] = row
+            covered = len(g1) > 0
+        else:
+            g2 = geoms_of.get(body_index.get(second, -1), ())
+            for a_ in g1:
+                for b_ in g2:
+                    geompair2data[(int(a_), int(b_))] = row
+                    pair_rows.append((int(a_), int(b_), row))
+            covered = len(g1) > 0 and len(g2) > 0
+        if not covered:
+            raise ValueError(f'contact sensor {(first, second)!r} matches no collision geom (bodies: {m.body_names})')
     sensor_maps['geompair2data'] = geompair2data
-    geompair2data_values = geompair2data.values()
-    for pair_i, pair in enumerate(contacts_pairs):
-        assert not isinstance(pair, str) and len(pair) == 2, f'Contact "{pair}" should be a pair of strings'
-        assert pair_i in geompair2data_values, f'Missing pair: {pair} ({body_names=})'
-    if contacts_pairs:
-        geom_sensor = -np.ones(max(m.ngeom, 1), np.int32)
-        pairs = []
-        for (g1, g2), row in geompair2data.items():
-            if g2 < 0:
-                geom_sensor[g1] = row
-            else:
-                pairs.append((g1, g2, row))
-        physics.set_contact_maps(len(contacts_pairs), geom_sensor, pairs)
+    if sensor_names:
+        physics.set_contact_maps(len(sensor_names), geom_sensor, pair_rows)
     return sensor_maps
 
 

@@ -194,6 +194,50 @@ class Simulation:
                 pylog.error(traceback.format_exc())
             raise err
 
+    # ---- checkpoint / resume ---------------------------------------------------------
+    def save_state(self, path: str, include_log: bool = True):
+        """Write everything a later ``load_state`` needs to continue this run bit for bit: mjData (``physics.get_state``), the
+        task's counters, the device controller's state (``state_dict()`` if it has one) and - ``include_log`` - the ring buffer
+        rows written so far.  One ``.npz`` file; call it between steps / launches."""
+        task = self.task
+        out = {f'physics/{k}': v for k, v in self.physics.get_state().items()}
+        out['task/counters'] = np.array([task.iteration, task.sim_iteration, task.n_iterations, task.substeps, task.buffer_size,
+                                         self.physics.n_envs], np.int64)
+        c = task._controller
+        if c is not None and hasattr(c, 'state_dict'):
+            out.update({f'controller/{k}': v for k, v in c.state_dict().items()})
+        if include_log and task.data is not None:
+            sens = task.data.sensors
+            for name in ('links', 'joints', 'xfrc', 'contacts'):
+                arr = getattr(sens, name).array
+                if arr is not None and arr.numel():
+                    out[f'log/{name}'] = arr.detach().cpu().numpy()
+        with open(path, 'wb') as f:
+            np.savez(f, **out)
+        return path
+
+    def load_state(self, path: str):
+        """Continue from a ``save_state`` file: same model, batch size, sub-steps and ring length (checked)."""
+        if self._needs_reset:
+            self.reset()
+        task = self.task
+        with np.load(path) as z:
+            it, sim_it, n_it, substeps, buffer_size, n_envs = (int(x) for x in z['task/counters'])
+            if (substeps, buffer_size, n_envs) != (task.substeps, task.buffer_size, self.physics.n_envs):
+                raise ValueError(f'checkpoint of {n_envs} envs, {substeps} sub-steps, ring of {buffer_size}; this simulation has '
+                                 f'{self.physics.n_envs}, {task.substeps}, {task.buffer_size}')
+            self.physics.set_state({k[len('physics/'):]: z[k] for k in z.files if k.startswith('physics/')})
+            task.iteration, task.sim_iteration = it, sim_it
+            c = task._controller
+            cs = {k[len('controller/'):]: z[k] for k in z.files if k.startswith('controller/')}
+            if cs:
+                c.load_state_dict(cs)
+            sens = task.data.sensors
+            for name in ('links', 'joints', 'xfrc', 'contacts'):
+                if f'log/{name}' in z.files:
+                    arr = getattr(sens, name).array
+                    arr.copy_(torch.as_tensor(z[f'log/{name}'], dtype=arr.dtype))
+
     def postprocess(self, iteration: int, log_path: str = '', plot: bool = False, **kwargs):
         """Postprocessing after simulation (reference simulation.py:181-213)."""
         if log_path:

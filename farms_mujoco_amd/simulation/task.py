@@ -120,6 +120,14 @@ class ExperimentTask:
         names = m.actuator_names
         dev = physics.device
         jn = self._controller.joints_names
+        # a device controller that integrates its own state advances once per ITERATION, by task.timestep - not by the model's
+        # timestep, which is timestep / num_sub_steps (the reference hands task.timestep to controller.step, task.py:293-300)
+        ct = getattr(self._controller, 'timestep', None)
+        if ct is not None and abs(ct - self.timestep) > 1e-9*self.timestep:
+            if getattr(self._controller, '_timestep_given', True):
+                raise ValueError(f'controller.timestep = {ct} but the task steps it once per iteration of {self.timestep} s '
+                                 f'({self.substeps} sub-steps of {self.sim_timestep} s)')
+            self._controller.timestep = float(self.timestep)
         self.maps['ctrl']['pos'] = torch.as_tensor([names.index(f'actuator_position_{j}') for j in jn[ControlType.POSITION]], device=dev)
         self.maps['ctrl']['vel'] = torch.as_tensor([names.index(f'actuator_velocity_{j}') for j in jn[ControlType.VELOCITY]], device=dev)
         self.maps['ctrl']['trq'] = torch.as_tensor([names.index(f'actuator_torque_{j}') for j in jn[ControlType.TORQUE]], device=dev)

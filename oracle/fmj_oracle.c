@@ -39,8 +39,31 @@ int fmjo_last_pgs_iterations(void) { return g_last_pgs_iterations; }   /* sweeps
  * scaled condition numbers 3e4 .. 2e5 for the models here); the GPU parity tests state their velocity / acceleration bounds as
  * small multiples of it instead of fitted numbers.  Read-only while a run is in flight. */
 static int g_fp32_storage = 0;
+/* Levels (round 5; VERDICT round 4 item 1: "the floor omits fp32 state and fp32 kinematics"):
+ *   1  M and H stored in fp32 (the round-3 knob, above);
+ *   2  + the STATE an fp32 engine carries from step to step - qpos, qvel, the solver's warm start - rounded to fp32 after every
+ *        step, and the kinematic poses every later stage reads (xpos, xquat / xmat, xipos / ximat, joint anchors and axes) rounded
+ *        to fp32 after mj_kinematics;
+ *   3  + every array handed from one stage to the next: cdof, cvel, qfrc_smooth, qacc_smooth, the constraint rows (J, aref, R).
+ * Arithmetic stays fp64 at every level: each level is "an fp64 engine whose only flaw is fp32 storage of those arrays" and what it
+ * differs from the plain run by is a floor for any engine that holds them in fp32. */
 void fmjo_set_fp32_storage(int on) { g_fp32_storage = on; }
-static void round_to_f32(double* a, int n) { for (int i = 0; i < n; i++) a[i] = (double)(float)a[i]; }
+/* fmjo_set_fp32_drop_bits(k): the rounding of the knob above keeps 24 - k mantissa bits instead of fp32's 24, i.e. 2^k times fp32's
+ * rounding error in every stored value - "what if the fp32 engine's per-step error were 2^k times the storage floor" (the walking-horizon
+ * study of tests/test_gpu_contacts.py::test_thousand_steps_of_walking and scripts/walk_event_diff.py). */
+static int g_fp32_drop_bits = 0;
+void fmjo_set_fp32_drop_bits(int k) { g_fp32_drop_bits = k < 0 ? 0 : (k > 20 ? 20 : k); }
+static void round_to_f32(double* a, int n) {
+  for (int i = 0; i < n; i++) {
+    float f = (float)a[i];
+    if (g_fp32_drop_bits && f == f && f != 0.0f && fabsf(f) < 1e30f) {
+      int ex; const double mant = frexp((double)f, &ex);                 /* f = mant 2^ex, 0.5 <= |mant| < 1 */
+      const double sc = ldexp(1.0, 24 - g_fp32_drop_bits);
+      f = (float)ldexp(nearbyint(mant * sc) / sc, ex);
+    }
+    a[i] = (double)f;
+  }
+}
 
 #define MINVAL 1e-15
 #define MAXVAL 1e10
@@ -239,6 +262,11 @@ static void kinematics(const fmj_model* m, ws_t* w, const double* qpos) {
     for (int k = 0; k < 3; k++) w->xipos[3 * i + k] = xpos[k] + v[k];
     mul_quat(iq, xquat, m->body_iquat + 4 * i);
     quat2mat(w->ximat + 9 * i, iq);
+  }
+  if (g_fp32_storage >= 2) {
+    round_to_f32(w->xpos, 3 * m->nbody); round_to_f32(w->xquat, 4 * m->nbody); round_to_f32(w->xmat, 9 * m->nbody);
+    round_to_f32(w->xipos, 3 * m->nbody); round_to_f32(w->ximat, 9 * m->nbody);
+    round_to_f32(w->xanchor, 3 * m->njnt); round_to_f32(w->xaxis, 3 * m->njnt);
   }
 }
 
@@ -1243,9 +1271,12 @@ static int forward(const fmj_model* m, ws_t* w, const double* qpos, const double
   xfrc_accumulate(m, w, xfrc);
   for (int i = 0; i < nv; i++)
     w->qfrc_smooth[i] = w->qfrc_passive[i] - w->qfrc_bias[i] + w->qfrc_actuator[i] + w->qfrc_xfrc[i];
+  if (g_fp32_storage >= 3) { round_to_f32(w->cdof, 6 * nv); round_to_f32(w->cvel, 6 * m->nbody); round_to_f32(w->qfrc_smooth, nv); }
   memcpy(w->qacc_smooth, w->qfrc_smooth, nv * sizeof(double));
   solve_ld(m, w->qacc_smooth, w->qLD, w->qLDiagInv);
+  if (g_fp32_storage >= 3) round_to_f32(w->qacc_smooth, nv);
   make_constraints(m, w, qpos, qvel, &warn);
+  if (g_fp32_storage >= 3) { round_to_f32(w->efc_J, w->nefc * nv); round_to_f32(w->efc_aref, w->nefc); round_to_f32(w->efc_R, w->nefc); }
   solve_constraints(m, w);
   sensors(m, w, qpos, qvel, sensordata);
   return warn;
@@ -1320,6 +1351,7 @@ static int step_one(const fmj_model* m, ws_t* w, double* qpos, double* qvel, con
   if (bad(w->qacc, m->nv)) warn |= FMJ_WARN_BADQACC;
   euler(m, w, qpos, qvel);
   memcpy(w->qacc_warmstart, w->qacc, m->nv * sizeof(double));
+  if (g_fp32_storage >= 2) { round_to_f32(qpos, m->nq); round_to_f32(qvel, m->nv); round_to_f32(w->qacc_warmstart, m->nv); }
   return warn;
 }
 

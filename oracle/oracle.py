@@ -38,15 +38,30 @@ def lib():
 
 class fp32_storage:
     """Context manager: inside it the oracle rounds the stored entries of M and H = M + h B to fp32 (nothing else), see
-    fmjo_set_fp32_storage in fmj_oracle.c.  ``with oracle.fp32_storage(): floor = oracle.step(...)``."""
+    fmjo_set_fp32_storage in fmj_oracle.c.  ``with oracle.fp32_storage(): floor = oracle.step(...)``.
+    ``level`` 2 adds the state carried from step to step (qpos, qvel, warm start) and the kinematic poses, 3 every array handed
+    between stages (cdof, cvel, qfrc_smooth, qacc_smooth, J, aref, R); the arithmetic stays fp64 at every level."""
+
+    def __init__(self, level=1, drop_bits=0):
+        self.level = int(level)
+        self.drop_bits = int(drop_bits)
 
     def __enter__(self):
-        lib().fmjo_set_fp32_storage(1)
+        lib().fmjo_set_fp32_drop_bits(self.drop_bits)
+        lib().fmjo_set_fp32_storage(self.level)
         return self
 
     def __exit__(self, *exc):
         lib().fmjo_set_fp32_storage(0)
+        lib().fmjo_set_fp32_drop_bits(0)
         return False
+
+
+def fp32_state(drop_bits=0):
+    """The yardstick VERDICT round 4 asked for: the fp64 oracle with qpos / qvel / warm start rounded to fp32 every step, fp32
+    kinematic poses and M, H stored in fp32 (level 2 of fmjo_set_fp32_storage).  ``drop_bits`` = k keeps 24 - k mantissa bits in
+    all of those: an fp64 engine with 2^k times fp32's storage error (fmjo_set_fp32_drop_bits)."""
+    return fp32_storage(2, drop_bits)
 
 
 def _d(a):

@@ -876,18 +876,22 @@ def test_two_env_kernel_modes_do_not_depend_on_the_partner(oracle, monkeypatch):
 @pytest.mark.parametrize('solver', ['newton', 'pgs'])
 def test_thousand_steps_of_walking(oracle, solver):
     """north_star's horizon on BASELINE configs[3]: qpos after 300 / 600 / 1000 free-running steps of the trot against the oracle's
-    own walk, 32 envs, rel = max |qpos - qpos_ref| / max |qpos_ref| per env, next to the same figure for the ORACLE ITSELF with its
-    mass matrix rounded to fp32 and nothing else changed (oracle.fp32_storage: the floor of any fp32 implementation).
-    Walking is not chaotic - a 1e-7 perturbation of the initial pose is 3e-7 after 1000 steps - but it is not smooth either: an env
-    whose foot lands or starts to slip within rounding of a step boundary takes the event one step earlier or later and is on
-    another (equally valid) walk from there on; the fp32-storage run of the fp64 oracle does exactly that in 2 of 8 envs between
-    step 600 and step 1000.
-    * Both solvers - Newton (the reference's fallback, mjcf.py:1348-1359) and PGS cut at 50 sweeps (configs[3] as BASELINE words it):
-      EVERY env within 1e-4, north_star's bound, after 300 steps (worst 1.2e-5); after 1000 steps the envs that took no event
-      differently are still within 1e-4 (7 of 32 with Newton, 13 of 32 with PGS; the fp64 oracle with an fp32 mass matrix: 21 and 18
-      of 32), the others are on another walk, up to 9e-2 of the pose away.
-    The bound that does not depend on events is per step: tests/test_gpu_teacher_forced.py (from the oracle's own state each of 8000
-    env-steps lands within 6e-5 (median) of the oracle's next state, 1 active-set flip, forces within 1.2e-5 of the largest force)."""
+    own walk, 32 envs, rel = max |qpos - qpos_ref| / max |qpos_ref| per env.
+
+    Walking is event-driven.  scripts/walk_event_diff.py (round 5, profiles/r05_walk_event_diff_*.txt) locates, per env, the first
+    step whose active set differs from the oracle's: 39 of 42 first differences are a GRAZING GROUND CONTACT - |dist| of 1e-9 ..
+    2e-7 m, the rounding of an fp32 position - on which the oracle, handed HIP's own state, decides as HIP does ("drift": the states
+    were 2e-6 .. 2e-5 apart by then); 3 are decisions on identical state at |dist| <= 7e-9 m.  An env that takes one such event a step
+    early or late is on another (equally valid) walk from there on.  How many envs are still within 1e-4 of the oracle's walk after
+    1000 steps is therefore a steep function of the PER-STEP error, and the yardsticks are fp64 engines with fp32 STORAGE:
+    * oracle.fp32_state(): qpos / qvel / warm start rounded to fp32 every step, fp32 poses, M and H stored in fp32 - the floor of any
+      fp32 engine (VERDICT round 4 asked for it): 19 / 32 (Newton) and 18 / 32 (PGS) envs within 1e-4 after 1000 steps;
+    * oracle.fp32_state(drop_bits=k): the same with 2^k times that storage error: x2 11 and 12 / 32, x4 5 and 7 / 32, x8 3 and 0 / 32.
+    The HIP step's per-step velocity error is 2.4x the floor's on this walk (teacher-forced, scripts/tf_probe.py: 4.6e-5 against
+    1.9e-5 rad/s median, equal parts entries of H and the fp32 L'DL) and it keeps 7 / 32 (Newton) and 13 - 17 / 32
+    (PGS): between the x2 and the x4 engine, where a 2.4x engine belongs.  The assertions below hold HIP to the x4 engine measured in
+    the same test (a regression of activation order or narrow phase would fall below it) and to north_star's bound for every env
+    at 300 steps; the bound that does not depend on events is per step, tests/test_gpu_teacher_forced.py."""
     import torch
     from farms_mujoco_amd.model import SOLVERS
     from farms_mujoco_amd.physics import BatchedPhysics
@@ -907,20 +911,25 @@ def test_thousand_steps_of_walking(oracle, solver):
         phys.step(Tm - done, ctrl_tape=tape_t[done:Tm].contiguous())
         torch.cuda.synchronize()
         done = Tm
-        ref = oracle.step(m, q32, v32, ctrl=tape64[:Tm], n_steps=Tm, ctrl_step_stride=n*m.nu, n_threads=8)
-        with oracle.fp32_storage():
-            fl = oracle.step(m, q32, v32, ctrl=tape64[:Tm], n_steps=Tm, ctrl_step_stride=n*m.nu, n_threads=8)
+        run = lambda: oracle.step(m, q32, v32, ctrl=tape64[:Tm], n_steps=Tm, ctrl_step_stride=n*m.nu, n_threads=8)
+        ref = run()
+        floors = {}
+        for k in (0, 1, 2):
+            with oracle.fp32_state(drop_bits=k):
+                floors[k] = rel(run()['qpos'], ref['qpos'])
         assert int(d.status.abs().sum()) == 0 and int(ref['status'].sum()) == 0
-        r, f = rel(d.qpos.cpu().numpy(), ref['qpos']), rel(fl['qpos'], ref['qpos'])
-        stats[Tm] = (r, f)
-        print(f'{solver} walk after {Tm:4d} steps: HIP median {np.median(r):.1e} worst {r.max():.1e}, within 1e-4: {(r <= 1e-4).sum()}/{n};   '
-              f'oracle with fp32 mass matrix: median {np.median(f):.1e} worst {f.max():.1e}, within 1e-4: {(f <= 1e-4).sum()}/{n}')
+        r = rel(d.qpos.cpu().numpy(), ref['qpos'])
+        stats[Tm] = (r, floors)
+        print(f'{solver} walk after {Tm:4d} steps: HIP median {np.median(r):.1e} worst {r.max():.1e}, within 1e-4: {(r <= 1e-4).sum()}/{n};   fp64 engine with '
+              + ', '.join(f'x{2**k} fp32 storage error: {(f <= 1e-4).sum()}/{n} (median {np.median(f):.1e})' for k, f in floors.items()))
     assert float(d.qpos[:, 2].min()) > 0.0 and float(d.qpos[:, 2].max()) < 0.1      # the plane holds the animal up
-    # measured (round 4, 32 envs; HIP / oracle with fp32 mass matrix, envs within 1e-4): Newton 32 / 32, 20 / 31, 7 / 21 after 300, 600, 1000
-    # steps; PGS x 50: 32 / 32, 25 / 30, 13 / 18.  Worst env after 1000 steps: 9e-2 (HIP), 6e-2 (the fp64 oracle with an fp32 mass matrix)
+    within = lambda x: int((x <= 1e-4).sum())
     assert (stats[300][0] <= 1e-4).all(), stats[300][0]                 # north_star's bound, every env, both solvers
     assert np.median(stats[600][0]) <= 1e-4
-    assert (stats[1000][0] <= 1e-4).sum() >= 4 and stats[1000][0].max() < 0.3
+    for Tm in (600, 1000):                                              # never below the fp64 engine with 4x fp32's storage error (3 envs of sampling noise)
+        r, floors = stats[Tm]
+        assert within(r) >= within(floors[2]) - 3, (Tm, within(r), {k: within(f) for k, f in floors.items()})
+    assert within(stats[1000][0]) >= 4 and stats[1000][0].max() < 0.3
     # an env that left the oracle's walk did so through an event, not through drift: it is either on it (1e-4) or far from it
     r = stats[1000][0]
     assert ((r <= 1e-4) | (r > 5e-4)).mean() > 0.8
@@ -1028,3 +1037,56 @@ def test_fused_walk_one_long_launch_equals_many_short_ones(oracle):
     for k in ('qpos', 'links'):
         assert _relerr(long_[k], short[k]) < 1e-3, k       # ... and its two routes stay together (measured 3e-6 of the pose)
     assert np.abs(c_long[-1][..., 2]).max() > 0.02         # the animals rest on the floor at the end
+
+
+def test_env_with_more_contacts_than_the_chip_holds_at_a_launch_boundary(oracle):
+    """an env that ENTERS a fused launch with more than 16 contacts is retired by the two-env kernel before
+    its first step and finished by the one-env kernel, which never writes the launch's first links row of an env it resumes - so the
+    two-env kernel has to, before it lets the env go.  Animals lying on their bellies (20 contacts from the reset's mj_forward on, 17+
+    for the first steps), launches of 2 steps so that several boundaries fall while the list is that long; every links / joints /
+    contact row is compared with the ORACLE's run (a second GPU run would skip the same rows)."""
+    import torch
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    m = _walker(spawn_z=0.06)
+    n, T = 6, 12
+    pairs = [(b, '') for b in m.body_names[1:] if b.endswith('_3') or b.startswith('body_')]
+    rng = np.random.default_rng(3)
+    q0 = np.tile(m.key_qpos, (n, 1)); q0[:, 7:] += rng.uniform(-0.05, 0.05, (n, m.nq - 7))
+    q0[:, 2] = 0.012                                        # on the belly
+    q0[n - 1, 2] = 0.04                                     # one animal on its feet: the partner of a retired half
+    data = AnimatData(m.timestep, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    sim = Simulation(m, m.body_names[1], SimulationOptions(timestep=m.timestep, n_iterations=T), n_envs=n, data=data, buffer_size=T)
+    sim.reset()
+    d = sim.physics.data
+    d.qpos[:] = torch.as_tensor(q0, dtype=torch.float32)
+    sim.physics.forward(disable_actuation=True)
+    assert sim.physics.kernel_info()['threads_per_env'] == 32
+    ncon0 = d.ncon.cpu().numpy().copy()
+    assert (ncon0[:n - 1] > 16).all() and ncon0[n - 1] <= 16, ncon0
+    q32 = d.qpos.cpu().numpy().astype(np.float64); v32 = d.qvel.cpu().numpy().astype(np.float64)
+    st = dict(qpos=q32, qvel=v32)
+    fds = [oracle.forward_debug(m, q32[e], v32[e]) for e in range(n)]
+    for k in ('xpos', 'xquat', 'xipos'):
+        st[k] = np.array([fd[k] for fd in fds])
+    sd = np.array([fd['sensordata'] for fd in fds]); sd[:, 6*(m.nbody - 1) + 3*m.n_sensor_joints:] = 0.0
+    st['sensordata'] = sd
+    seen = []
+    while sim.task.sim_iteration < T:
+        seen.append(d.ncon.cpu().numpy().copy())
+        sim.step_fused(2)
+    torch.cuda.synchronize()
+    assert int((d.status & ~8).abs().sum()) == 0
+    assert sum(int((s_[:n - 1] > 16).any()) for s_ in seen) >= 2, seen      # boundaries with a list too long for the chip: the first and later ones
+    g2d = sim.task.maps['sensors']['geompair2data']
+    ref = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                           n_contact_rows=len(pairs), n_threads=4)
+    links = data.sensors.links.array.cpu().numpy()
+    assert np.abs(links[:, :, :, 7:10]).min(axis=(2, 3)).max() < 1.0 and np.abs(links[..., 3:7]).max(axis=(2, 3)).min() > 0.5, 'a links row was never written'
+    for it in range(T):
+        assert _relerr(links[it], ref['links'][it]) < 2e-3, (it, _relerr(links[it], ref['links'][it]))
+    assert _relerr(links[0], ref['links'][0]) < 1e-6        # row 0 holds the reset's poses: no dynamics in it yet
+    rows = data.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
+    scale = np.abs(want[..., :9]).max()
+    assert np.abs(rows[..., :9] - want[..., :9]).max()/scale < 2e-2 and scale > 0.05
