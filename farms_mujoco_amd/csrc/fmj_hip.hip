@@ -1825,6 +1825,10 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : nullptr;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : nullptr;
   return nullptr;
+#elif defined(FMJ_DEV_CONS2_FUSED_ONLY)      // development build: the fused two-env constraint kernel alone (resource remarks, ISA listings)
+  (void)cons;
+  if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : nullptr;
+  return nullptr;
 #elif defined(FMJ_DEV_CONS2_ONLY)      // development build: only the two-env constraint kernel and its one-env fallback (compile time)
   if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_cons2_kernel<false, FMJ_TU_MAXD>;
   if (cons == 1 && dual == 0) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;

@@ -39,10 +39,10 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     # Contact sensors.  Contract of reference physics.py:360-382: ``geompair2data`` maps (geom, -1) to the row of the sensor named
     # (body of geom, '') and (geom1, geom2) to the row of the sensor named (body1, body2), every geom of a body counting for its body.
     # Built from a body -> geoms table: a sensor row fans out to its body's geoms (or the product of two bodies' geoms).
-    sensor_names = list(sensor_data.contacts.names)
+    sensor_names = list(sensor_data.contacts.names)      # (errors are AssertionError, as the reference's asserts raise)
     for name in sensor_names:
         if isinstance(name, str) or len(name) != 2:
-            raise ValueError(f'contact sensor {name!r}: expected a (body, body-or-empty) pair of strings')
+            raise AssertionError(f'contact sensor {name!r}: expected a (body, body-or-empty) pair of strings')
     body_index = {name: b for b, name in enumerate(m.body_names)}
     geom_body = np.asarray(m.geom_bodyid[:m.ngeom], np.int64)
     geoms_of = {b: np.nonzero(geom_body == b)[0] for b in np.unique(geom_body)}
@@ -50,7 +50,7 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     geom_sensor = np.full(max(m.ngeom, 1), -1, np.int32)
     pair_rows = []
     if len(set(map(tuple, sensor_names))) != len(sensor_names):      # the reference's "Missing pair" assertion fires on a repeated name too
-        raise ValueError(f'contact sensor names must be unique: {sensor_names}')
+        raise AssertionError(f'contact sensor names must be unique: {sensor_names}')
     for row, (first, second) in enumerate(sensor_names):
         g1 = geoms_of.get(body_index.get(first, -1), ())
         if second == '':
@@ -66,7 +66,7 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
                     pair_rows.append((int(a_), int(b_), row))
             covered = len(g1) > 0 and len(g2) > 0
         if not covered:
-            raise ValueError(f'contact sensor {(first, second)!r} matches no collision geom (bodies: {m.body_names})')
+            raise AssertionError(f'contact sensor {(first, second)!r} matches no collision geom (bodies: {m.body_names})')
     sensor_maps['geompair2data'] = geompair2data
     if sensor_names:
         physics.set_contact_maps(len(sensor_names), geom_sensor, pair_rows)

@@ -29,6 +29,8 @@
 
 /* diagnostics: sweeps the last PGS solve ran (single-threaded use only) */
 static int g_last_pgs_iterations = 0;
+static int g_last_noslip_iterations = 0;
+int fmjo_last_noslip_iterations(void) { return g_last_noslip_iterations; }
 int fmjo_last_pgs_iterations(void) { return g_last_pgs_iterations; }   /* sweeps / iterations of the last solve, any solver */
 
 #include "../include/fmj.h"
@@ -970,14 +972,9 @@ static double dual_cost(const ws_t* w, const double* f) {
   return c;
 }
 
-static void solve_primal(const fmj_model* m, ws_t* w, int newton);
-static void solve_constraints(const fmj_model* m, ws_t* w) {
+/* AR = J M^-1 J' + R ; b = J qacc_smooth - aref (mj_projectConstraint + the dual's linear term) */
+static void build_dual(const fmj_model* m, ws_t* w) {
   int nv = m->nv, n = w->nefc;
-  memset(w->qfrc_constraint, 0, nv * sizeof(double));
-  memset(w->jointlimitfrc, 0, m->njnt * sizeof(double));
-  if (n == 0) { memcpy(w->qacc, w->qacc_smooth, nv * sizeof(double)); g_last_pgs_iterations = 0; return; }
-  if (m->solver == FMJ_SOLVER_NEWTON || m->solver == FMJ_SOLVER_CG) { solve_primal(m, w, m->solver == FMJ_SOLVER_NEWTON); return; }
-  /* AR = J M^-1 J' + R ; b = J qacc_smooth - aref */
   for (int e = 0; e < n; e++) {
     double* x = w->efc_MiJT + (size_t)e * nv;
     memcpy(x, w->efc_J + (size_t)e * nv, nv * sizeof(double));
@@ -988,6 +985,111 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
     w->efc_AR[(size_t)i * n + i] += w->efc_R[i];
     w->efc_b[i] = dotn(w->efc_J + (size_t)i * nv, w->qacc_smooth, nv) - w->efc_aref[i];
   }
+}
+
+/* qfrc_constraint = J' f, the joint-limit sensor forces, qacc = qacc_smooth + M^-1 qfrc_constraint (MuJoCo's dualFinish) */
+static void dual_finish(const fmj_model* m, ws_t* w) {
+  int nv = m->nv, n = w->nefc;
+  memset(w->qfrc_constraint, 0, nv * sizeof(double));
+  memset(w->jointlimitfrc, 0, m->njnt * sizeof(double));
+  for (int e = 0; e < n; e++) {
+    for (int i = 0; i < nv; i++) w->qfrc_constraint[i] += w->efc_J[(size_t)e * nv + i] * w->efc_force[e];
+    if (w->efc_type[e] == EFC_LIMIT) w->jointlimitfrc[w->efc_id[e]] += w->efc_force[e];
+  }
+  memcpy(w->qacc, w->qfrc_constraint, nv * sizeof(double));
+  solve_ld(m, w->qacc, w->qLD, w->qLDiagInv);
+  for (int i = 0; i < nv; i++) w->qacc[i] += w->qacc_smooth[i];
+}
+
+static int qcqp2(double* res, const double A_[4], const double b_[2], const double d[2], double r);
+
+/* mj_solNoSlip (option.noslip_iterations, reference mjcf.py:1392-1403), restated from MuJoCo's documentation and solver source
+ * as recalled [MJ-knowledge]; parity unpinned like the rest.  A post-pass after the main solver, whatever it was: Gauss-Seidel on the
+ * dual problem WITHOUT the regulariser R, over the friction dimensions of the contacts only - the normal forces (and the limit
+ * rows) keep the values the main solver gave them, so the soft contact still yields along its normal, but the friction forces are
+ * re-solved as hard constraints: a sticking contact ends up with zero tangential acceleration instead of the slow creep the
+ * regulariser allows.
+ *   pyramidal contact: its rows come in opposing pairs (j, j + 1) = normal +- mu tangent.  The pair's sum (its share of the normal
+ *     force) stays fixed, mid = (f_j + f_j+1) / 2; the difference y is minimised exactly: with the 2 x 2 block Ac of A (R removed)
+ *     and bc = residual - Ac f_old,  K1 = Ac00 + Ac11 - 2 Ac01,  K0 = mid (Ac00 - Ac11) + bc0 - bc1,  y = -K0 / K1 clamped to
+ *     [-mid, mid], f = (mid + y, mid - y);
+ *   elliptic contact: with the normal force fixed, the friction forces solve the QCQP  min 0.5 v'Ac v + v'bc,  |v / mu| <= f_n
+ *     (mju_QCQP2 for condim 3), rescaled onto the cone when the constraint is active.
+ * A sweep's improvement (decrease of the unregularised dual cost; the first sweep adds the regulariser's share 0.5 R f^2 of the
+ * main solver's forces) times 1 / (meaninertia max(1, nv)) is tested against noslip_tolerance. */
+static void noslip(const fmj_model* m, ws_t* w) {
+  const int n = w->nefc, nv = m->nv;
+  if (n == 0 || m->noslip_iterations <= 0 || w->ncon == 0) return;
+  if (m->solver == FMJ_SOLVER_NEWTON || m->solver == FMJ_SOLVER_CG) build_dual(m, w);      /* the primal solvers never form A */
+  double* f = w->efc_force;
+  const double scale = 1.0 / (w->meaninertia * (nv > 1 ? nv : 1));
+#define A_(i_, j_) (w->efc_AR[(size_t)(i_) * n + (j_)] - ((i_) == (j_) ? w->efc_R[i_] : 0.0))
+  int iter = 0;
+  while (iter < m->noslip_iterations) {
+    double improvement = 0;
+    if (iter == 0) for (int i = 0; i < n; i++) improvement += 0.5 * f[i] * f[i] * w->efc_R[i];
+    for (int c = 0; c < w->ncon; c++) {
+      const int i = w->con_efc[c];
+      if (m->cone == FMJ_CONE_ELLIPTIC) {
+        if (i + 3 > n) continue;
+        double res[3], old[3] = {f[i], f[i + 1], f[i + 2]};
+        for (int j = 0; j < 3; j++) { res[j] = w->efc_b[i + j]; for (int k = 0; k < n; k++) res[j] += A_(i + j, k) * f[k]; }
+        if (f[i] < MINVAL) f[i + 1] = f[i + 2] = 0;
+        else {
+          double Ac[4] = {A_(i + 1, i + 1), A_(i + 1, i + 2), A_(i + 2, i + 1), A_(i + 2, i + 2)}, bc[2], d[2] = {w->con_mu[c], w->con_mu[c]}, v[2];
+          for (int j = 0; j < 2; j++) bc[j] = res[1 + j] - Ac[2 * j] * old[1] - Ac[2 * j + 1] * old[2];
+          if (qcqp2(v, Ac, bc, d, f[i])) {
+            double sv = (v[0] / d[0]) * (v[0] / d[0]) + (v[1] / d[1]) * (v[1] / d[1]);
+            sv = sqrt(f[i] * f[i] / fmax(MINVAL, sv));
+            v[0] *= sv; v[1] *= sv;
+          }
+          f[i + 1] = v[0]; f[i + 2] = v[1];
+        }
+        double dl[3] = {0, f[i + 1] - old[1], f[i + 2] - old[2]}, change = 0;
+        for (int j = 1; j < 3; j++) { change += dl[j] * res[j]; for (int k = 1; k < 3; k++) change += 0.5 * dl[j] * A_(i + j, i + k) * dl[k]; }
+        if (change > 1e-10) { f[i + 1] = old[1]; f[i + 2] = old[2]; change = 0; }
+        improvement -= change;
+        continue;
+      }
+      if (i + 4 > n) continue;
+      for (int j = i; j < i + 4; j += 2) {
+        double res[2], old[2] = {f[j], f[j + 1]};
+        for (int r = 0; r < 2; r++) { res[r] = w->efc_b[j + r]; for (int k = 0; k < n; k++) res[r] += A_(j + r, k) * f[k]; }
+        const double Ac[4] = {A_(j, j), A_(j, j + 1), A_(j + 1, j), A_(j + 1, j + 1)};
+        const double bc0 = res[0] - Ac[0] * old[0] - Ac[1] * old[1], bc1 = res[1] - Ac[2] * old[0] - Ac[3] * old[1];
+        const double mid = 0.5 * (old[0] + old[1]);
+        const double K1 = Ac[0] + Ac[3] - Ac[1] - Ac[2], K0 = mid * (Ac[0] - Ac[3]) + bc0 - bc1;
+        if (K1 < MINVAL) f[j] = f[j + 1] = mid;
+        else {
+          const double y = -K0 / K1;
+          if (y < -mid) { f[j] = 0; f[j + 1] = 2 * mid; }
+          else if (y > mid) { f[j] = 2 * mid; f[j + 1] = 0; }
+          else { f[j] = mid + y; f[j + 1] = mid - y; }
+        }
+        const double dl[2] = {f[j] - old[0], f[j + 1] - old[1]};
+        double change = dl[0] * res[0] + dl[1] * res[1] + 0.5 * (dl[0] * (Ac[0] * dl[0] + Ac[1] * dl[1]) + dl[1] * (Ac[2] * dl[0] + Ac[3] * dl[1]));
+        if (change > 1e-10) { f[j] = old[0]; f[j + 1] = old[1]; change = 0; }
+        improvement -= change;
+      }
+    }
+#undef A_
+    iter++;
+    if (improvement * scale < m->noslip_tolerance) break;
+#define A_(i_, j_) (w->efc_AR[(size_t)(i_) * n + (j_)] - ((i_) == (j_) ? w->efc_R[i_] : 0.0))
+  }
+#undef A_
+  g_last_noslip_iterations = iter;
+  dual_finish(m, w);
+}
+
+static void solve_primal(const fmj_model* m, ws_t* w, int newton);
+static void solve_constraints(const fmj_model* m, ws_t* w) {
+  int nv = m->nv, n = w->nefc;
+  memset(w->qfrc_constraint, 0, nv * sizeof(double));
+  memset(w->jointlimitfrc, 0, m->njnt * sizeof(double));
+  if (n == 0) { memcpy(w->qacc, w->qacc_smooth, nv * sizeof(double)); g_last_pgs_iterations = 0; return; }
+  if (m->solver == FMJ_SOLVER_NEWTON || m->solver == FMJ_SOLVER_CG) { solve_primal(m, w, m->solver == FMJ_SOLVER_NEWTON); noslip(m, w); return; }
+  build_dual(m, w);
   /* warm start from previous qacc (mj_fwdConstraint) */
   {
     double* jar = dalloc(n);
@@ -1016,13 +1118,8 @@ static void solve_constraints(const fmj_model* m, ws_t* w) {
     g_last_pgs_iterations = it + 1;
     if (improvement * scale < m->solver_tolerance) break;
   }
-  for (int e = 0; e < n; e++) {
-    for (int i = 0; i < nv; i++) w->qfrc_constraint[i] += w->efc_J[(size_t)e * nv + i] * w->efc_force[e];
-    if (w->efc_type[e] == EFC_LIMIT) w->jointlimitfrc[w->efc_id[e]] += w->efc_force[e];
-  }
-  memcpy(w->qacc, w->qfrc_constraint, nv * sizeof(double));
-  solve_ld(m, w->qacc, w->qLD, w->qLDiagInv);
-  for (int i = 0; i < nv; i++) w->qacc[i] += w->qacc_smooth[i];
+  dual_finish(m, w);
+  noslip(m, w);
 }
 
 /* ------------------------------------------------------------------------------------------ */

@@ -263,3 +263,69 @@ def test_sliding_slab_obeys_coulomb_momentum_balance(oracle):
     assert abs(out['elliptic', 0.0][0] - out['elliptic', 0.0][2]) < 1e-6*g and abs(out['pyramidal', 0.0][0] - out['pyramidal', 0.0][2]) < 1e-6*g
     assert abs(out['elliptic', 0.5][0] - out['elliptic', 0.5][2]) < 2e-3*out['elliptic', 0.5][2] and abs(out['elliptic', 0.5][1]) < 1e-3
     assert abs(out['pyramidal', 0.5][0] - out['pyramidal', 0.5][2]) > 0.1*out['pyramidal', 0.5][2]
+
+
+def _slab_on_incline(th, mu, yaw=0.3):
+    g = 9.81
+    b = ModelBuilder('slab', timestep=1e-3, gravity=(g*np.sin(th)*np.cos(yaw), g*np.sin(th)*np.sin(yaw), -g*np.cos(th)))
+    b.add_body('slab', 'world', pos=(0, 0, 0.02), mass=1.0, inertia=(4e-3, 4e-3, 8e-3), joint='free')
+    b.add_geom('slab', GEOM_BOX, (0.1, 0.1, 0.02), friction=(mu, 0, 0))
+    b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(mu, 0, 0))
+    b.options['max_contacts'] = 8
+    return b.compile()
+
+
+@pytest.mark.parametrize('cone', ['pyramidal', 'elliptic'])
+@pytest.mark.parametrize('solver', ['pgs', 'newton'])
+def test_noslip_stops_the_creep_of_a_sticking_contact(oracle, cone, solver):
+    """option.noslip_iterations (reference mjcf.py:1392-1403): MuJoCo's post-pass re-solves the FRICTION forces without the
+    regulariser, the normal forces keep the main solver's values.  A slab at rest on an incline it can hold (mu > tan theta) creeps
+    under the soft constraint - the regulariser lets the friction rows yield - and stops creeping with noslip: for a contact that
+    sticks, the unregularised rows give J_t qacc = aref_t = -B v_t, which is 0 from rest.  Checked after the slab has settled on its
+    soft contacts: tangential velocity of the CoM after 300 steps with and without the post-pass, the normal forces the two runs
+    carry, and - property of the pass itself - a sweep never raises the unregularised dual cost (improvement >= 0 is what ends it)."""
+    th, mu = 0.3, 0.6                       # tan(0.3) = 0.31 < 0.6: sticks
+    m = _with(_slab_on_incline(th, mu), solver, 100 if solver == 'newton' else 200, 1e-10)
+    m.cone = CONES[cone]
+    res = {}
+    for ns in (0, 50):
+        m.noslip_iterations = ns; m.noslip_tolerance = 1e-12
+        q = m.qpos0[None].copy(); v = np.zeros((1, m.nv)); w = np.zeros((1, m.nv))
+        for t in range(300):
+            o = oracle.step_tf(m, q, v, warmstart=w, want_AR=False)
+            q, v, w = o['qpos'], o['qvel'], o['warmstart']
+        nc = int(o['ncon'][0])
+        assert nc == 4 and int(o['status'][0]) == 0
+        res[ns] = dict(vt=np.hypot(v[0, 0], v[0, 1]), fn=o['contact'][0, :nc, 12].sum(), q=q.copy())
+    print(f"{cone} {solver}: tangential creep velocity without / with noslip {res[0]['vt']:.3e} / {res[50]['vt']:.3e}; normal force {res[0]['fn']:.6f} / {res[50]['fn']:.6f}")
+    assert res[0]['vt'] > 1e-5                                   # the soft contact creeps down the slope ...
+    assert res[50]['vt'] < 1e-2*res[0]['vt']                     # ... noslip holds it (measured: 300 times slower)
+    assert abs(res[50]['fn'] - 9.81*np.cos(th)) < 2e-3*9.81 and abs(res[0]['fn'] - 9.81*np.cos(th)) < 2e-3*9.81      # both carry the weight's normal part
+
+
+def test_noslip_keeps_normal_and_limit_forces_and_zero_iterations_is_the_identity(oracle):
+    """One step of the walker (feet, bellies, a joint on its limit) with and without the post-pass: every limit-row force and every
+    contact's normal force (the sum of its four pyramid rows) is what the main solver left; the friction forces move; with
+    noslip_iterations = 0 nothing changes at all."""
+    m = _walker()
+    qs, vs = _states(m, 6, seed=4)
+    base = oracle.step_tf(_with(m, 'pgs', 200, 1e-12), qs, vs, want_AR=False)
+    mm = _with(m, 'pgs', 200, 1e-12); mm.noslip_iterations = 0
+    same = oracle.step_tf(mm, qs, vs, want_AR=False)
+    assert np.array_equal(base['qvel'], same['qvel']) and np.array_equal(base['efc'], same['efc'])
+    mm.noslip_iterations = 20; mm.noslip_tolerance = 1e-12
+    ns = oracle.step_tf(mm, qs, vs, want_AR=False)
+    moved = 0
+    for e in range(qs.shape[0]):
+        ne, nc = int(base['nefc'][e]), int(base['ncon'][e])
+        assert ne == int(ns['nefc'][e]) and nc == int(ns['ncon'][e])
+        nlim = ne - 4*nc
+        fb, fn = base['efc'][e, :ne, 0], ns['efc'][e, :ne, 0]
+        assert np.array_equal(fb[:nlim], fn[:nlim])                                              # limit rows untouched
+        for c in range(nc):
+            a, b_ = fb[nlim + 4*c:nlim + 4*c + 4], fn[nlim + 4*c:nlim + 4*c + 4]
+            assert abs(a[:2].sum() - b_[:2].sum()) < 1e-12*max(1.0, a.sum()) and abs(a[2:].sum() - b_[2:].sum()) < 1e-12*max(1.0, a.sum())
+            assert (b_ >= 0).all()
+            moved += int(np.abs(a - b_).max() > 1e-9)
+    assert moved > 0
+    assert not np.array_equal(base['qvel'], ns['qvel'])
