@@ -231,7 +231,8 @@ def api_paths(n_envs, chunk, device):
         dt = time.perf_counter() - t0
         steps = (n_it - warm)*sub
         out[name] = {'value': n_envs*steps/dt, 'unit': 'env-steps/s', 'iterations': n_it - warm, 'substeps': sub,
-                     'call': f'Simulation.run(fused={fused}), ring of {chunk} rows' + ('' if fused else ': fmj_physics2data + fmj_drag + ctrl write + fmj_step(1) per step')}
+                     'call': f'Simulation.run(fused={fused}), ring of {chunk} rows' + ('' if fused else ': two launches per step - fmj_before_step (rows + drag), then the step with the device controller '
+                                                                                                   '(round 4: fmj_physics2data + fmj_drag + torch ctrl write + fmj_step)')}
         del sim
     return out
 
@@ -260,8 +261,9 @@ def main():
                     help='steps per fused launch = ring-buffer length.  1000 = the reference logs a whole 1000-iteration run (AnimatData of n_iterations '
                          'rows, task.py:62,158); 100 was the default up to round 4 and is what every same-box A/B of DESIGN.md used.  Longer launches '
                          'amortise prologue / epilogue and - walking - average the uneven contact load of the waves of the one resident round')
-    ap.add_argument('--min-seconds', type=float, default=2.0,
-                    help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block)')
+    ap.add_argument('--min-seconds', type=float, default=6.0,
+                    help='the timed region repeats the --steps block until it lasts at least this long (0: exactly one block); 6 s so that an '
+                         'external sampler with a 5 s period sees the GPU busy (VERDICT round 4: with 2 s the driver\'s gpu_busy read 2 %%)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the short walk / mixed measurements appended to the swim line')
     ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh', 'walk_newton', 'walk_cg', 'walk_elliptic', 'walk_pairs_newton'],
@@ -365,14 +367,50 @@ def main():
     for s_ in sims:
         s_.physics.check_invalid_state()
 
+    # N > 1: the other sharded BASELINE configurations next to the 4096-per-GPU headline, so that ONE driver run records them
+    # (VERDICT round 4 item 6): configs[2] = 8192 swimming salamanders per GPU, configs[4] = the mixed batch, bucket then split (every
+    # rank holds its share of the eels and of the centipedes).  Same protocol: barrier, K steps in launches of `chunk`, barrier, MAX.
+    b = algorithmic_bytes_per_env_step(m, sim, args.workload, sims)
+    info = sim.physics.kernel_info()
+    has_constraints = sim.physics.has_constraints
+    sharded = None
+    if world > 1 and not args.no_extras and args.workload == 'swim':
+        sharded = {}
+        del batch, sims, sim
+        torch.cuda.empty_cache()
+        for name, per_gpu in (('configs[2]: swim, 8192 envs per GPU', 8192), ('configs[4]: mixed eel + centipede, bucket then split', n_envs)):
+            ck = min(chunk, 250)              # (a ring of 250 rows: 8192 swimmers x 1000 rows would be 34 GB)
+            if name.startswith('configs[4]'):
+                sm = [build_sim(per_gpu//2, n_it, ck, rank*(per_gpu//2), device, morphology='eel')[0],
+                      build_sim(per_gpu - per_gpu//2, n_it, ck, world*(per_gpu//2) + rank*(per_gpu - per_gpu//2), device, morphology='centipede')[0]]
+            else:
+                sm = [build_sim(per_gpu, n_it, ck, rank*per_gpu, device)[0]]
+            bt = BucketedSimulation(sm)
+            for _ in range(4):
+                bt.step_fused(ck)
+            torch.cuda.synchronize()
+            dist.barrier()
+            t1 = time.perf_counter()
+            nl = 8
+            for _ in range(nl):
+                bt.step_fused(ck)
+            torch.cuda.synchronize()
+            own = time.perf_counter() - t1
+            dist.barrier()
+            dts = max_over_ranks(time.perf_counter() - t1, device=device if args.dist_backend == 'nccl' else None)
+            for s_ in sm:
+                s_.physics.check_invalid_state()
+            sharded[name] = {'value': per_gpu*world*nl*ck/dts, 'unit': 'env-steps/s', 'envs_per_gpu': per_gpu, 'n_gpus': world, 'steps': nl*ck,
+                             'steps_per_launch': ck, 'timed_region_s': dts, 'this_rank_s': own, 'scaling': 'weak'}
+            del bt, sm
+            torch.cuda.empty_cache()
+
     if rank == 0:
         # dominant kernel = the fused step kernel; HIP events on the launch stream around every launch
         full = np.array([e0.elapsed_time(e1)*1e-3 for e0, e1, c in evs if c == chunk] or [e0.elapsed_time(e1)*1e-3*chunk/c for e0, e1, c in evs])
         avg_launch_s = float(full.mean())
-        b = algorithmic_bytes_per_env_step(m, sim, args.workload, sims)
         alg_bytes_per_launch = b['full']*n_envs*chunk
         achieved = alg_bytes_per_launch/avg_launch_s/1e9
-        info = sim.physics.kernel_info()
         # HBM bytes and issue shares from the PMC passes (rocprofv3 cannot run inside this process): the committed summary
         # of the same workload, per env-step, produced as DESIGN.md section 5 describes (scripts/pmc_summary.py)
         traffic, binding, src = None, None, None
@@ -423,11 +461,12 @@ def main():
             'roofline': {'bound': 'hbm', 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved/HBM_PEAK_GBS, 'traffic': traffic,
                          'frac_log_only': b['log']*n_envs*chunk/avg_launch_s/1e9/HBM_PEAK_GBS,
+                         'frac_traffic': (traffic/avg_launch_s/1e9/HBM_PEAK_GBS) if traffic is not None else None,
                          'traffic_note': ('HBM bytes per launch, FETCH_SIZE + WRITE_SIZE per env-step as counted by the PMC passes '
                                           f'({src}) x envs x steps per launch; algorithmic = {alg_bytes_per_launch}') if traffic is not None else
                                          (f'null: {stale}' if stale else 'null: no PMC summary of this workload / batch size under profiles/'),
                          'kernel': (('fmj_step_cons2_kernel<true, MAXD> (two envs per wave; envs beyond 64 constraint rows finish in fmj_step_kernel<true, MAXD, CONS>)'
-                                     if sim.physics.has_constraints else 'fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)') if info['threads_per_env'] == 32
+                                     if has_constraints else 'fmj_step_dual2_kernel<true, MAXD, WPS> (two envs per wave)') if info['threads_per_env'] == 32
                                     else 'fmj_step_kernel<true, MAXD, CONS> (one env per wave)'),
                          'avg_launch_ms': avg_launch_s*1e3,
                          'algorithmic_bytes_per_env_step': b['full'],
@@ -435,9 +474,14 @@ def main():
                                                    + '; B_core (state + ctrl) stays on chip between the steps of a fused launch, so '
                                                      'frac_log_only counts the row payload alone (SURVEY 8d)',
                          'binding': binding,
+                         'frac_note': 'frac prices B_full = B_core + B_log, but B_core (state + ctrl, 860 B for salamander-33) stays on chip between the steps '
+                                      'of a fused launch and never crosses HBM; frac_log_only prices the row payload alone, frac_traffic the bytes the PMC '
+                                      'counters saw (the rows as stored, dead columns of the 48-byte joint rows included): the two that describe bytes that move',
                          'note': 'the step is bound by dependent-chain latency and VALU issue of the tree recursions, not by HBM '
                                  '(binding: share of SQ_WAVE_CYCLES by SQ counter, profiles/): HBM is the nominal bound (SURVEY 8d)'},
         }
+        if sharded is not None:
+            out['sharded_configs'] = sharded
         if world == 1 and not args.no_extras and args.workload == 'swim':
             # the other BASELINE configurations, briefly, so that the driver's record carries them too (never the headline)
             try:

@@ -58,7 +58,11 @@ class CFusedArgs(ctypes.Structure):
                 ('row_stride_joints', ctypes.c_int64), ('row_stride_xfrc', ctypes.c_int64),
                 ('row_stride_contacts', ctypes.c_int64),
                 ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP),
-                ('env_order', _VP), ('substeps', ctypes.c_int32), ('substep_links', ctypes.c_int32)]
+                ('env_order', _VP), ('substeps', ctypes.c_int32), ('substep_links', ctypes.c_int32),
+                ('n_iterations', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
+
+
+BEFORE_ROWS, BEFORE_LINKS_ONLY, BEFORE_CONTACTS, BEFORE_DRAG = 1, 2, 4, 8      # FMJ_BEFORE_* of include/fmj.h
 
 
 # every symbol include/fmj.h declares: name -> (restype, argtypes)
@@ -91,6 +95,8 @@ SYMBOLS = {
     'fmj_physics2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits),
                                         ctypes.c_int32, _VP]),
     'fmj_set_contact_maps': (ctypes.c_int, [_VP, ctypes.c_int32, _I, ctypes.c_int32, _I]),
+    'fmj_before_step': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CWater), ctypes.POINTER(CUnits),
+                                       ctypes.c_int32, _VP, _VP]),
     'fmj_contacts2data': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CRows), ctypes.POINTER(CUnits), _VP]),
     'fmj_step_fused': (ctypes.c_int, [_VP, ctypes.POINTER(CData), ctypes.POINTER(CFusedArgs), _VP]),
     'fmj_sc': (ctypes.c_int, [ctypes.c_char_p]),
@@ -112,7 +118,7 @@ def build_id() -> str:
 
 
 _lib = None
-ABI_VERSION = 5         # FMJ_ABI_VERSION of include/fmj.h
+ABI_VERSION = 6         # FMJ_ABI_VERSION of include/fmj.h
 
 
 def build(force: bool = False, verbose: bool = False, defines=(), out: str = None) -> str:

@@ -97,6 +97,7 @@ struct DevModel {
   int cons;                   // 1 if the model has limits or collision geoms
   int ngeom, nplane, max_contacts, maxefc, solver_iterations, nvs;   // nvs = odd row stride of the Jacobian rows
   float solver_tolerance, pgs_scale, impratio_isqrt;
+  int noslip_iterations; float noslip_tolerance;      // option.noslip_iterations / noslip_tolerance (mjcf.py:1392-1403): the post-pass of fmj_cons_rows.inc
   int cone;                   // FMJ_CONE_PYRAMIDAL, or FMJ_CONE_ELLIPTIC (Newton / CG only: three rows per contact, cone cost in fmj_newton.inc)
   int solver, ls_iterations;  // FMJ_SOLVER_PGS, or FMJ_SOLVER_NEWTON / FMJ_SOLVER_CG (both the NEWTON instantiation of the constraint kernel); line search
   float ls_tolerance;
@@ -162,6 +163,7 @@ struct StepArgs {
   float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
   float* qacc_warmstart; float* contact; int* ncon; float* contacts_rows; float inv_newtons;
   int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
+  int n_it_total;             // fused: fmj_fused_args::n_iterations (0 = unknown): a sub-step whose task.iteration reached it writes no rows
   int substeps, sub_links;    // fused: physics steps per iteration (>= 1); sub-steps write links-only rows + drag (include/fmj.h)
   long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc, row_stride_contacts;
   int n_contact_rows, n_pairs; const int* geom_sensor; const int* pairs;
@@ -829,6 +831,36 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
   *kimp = K * imp; *bb = B;
 }
 
+// ---- elliptic cone on the dual side (mj_solPGS's block update, the noslip pass): oracle cone_zone / qcqp2 / pgs_elliptic_block in fp32
+// forces of one elliptic contact at the residuals jar = (normal, tangent 1, tangent 2): mj_constraintUpdate's three zones (the warm start)
+__device__ __forceinline__ void ell_zone_forces(float j0, float j1, float j2, float D0, float fr, float isq, float* f0, float* f1, float* f2) {
+  const float mus = fr * isq;
+  const float U1 = j1 * fr, U2 = j2 * fr, N = j0 * mus, T = sqrtf(U1 * U1 + U2 * U2);
+  if (N >= mus * T || (T <= 0.f && N >= 0.f)) { *f0 = 0.f; *f1 = 0.f; *f2 = 0.f; }
+  else if (mus * N + T <= 0.f || (T <= 0.f && N < 0.f)) { const float Dt = D0 * fr * fr / (mus * mus); *f0 = -D0 * j0; *f1 = -Dt * j1; *f2 = -Dt * j2; }
+  else { const float Dm = D0 / (mus * mus * (1.f + mus * mus)); const float NmT = N - mus * T; *f0 = -Dm * NmT * mus; const float sc = -(*f0) / T * fr; *f1 = sc * U1; *f2 = sc * U2; }
+}
+// mju_QCQP2: min 0.5 x'A x + x'b  s.t.  sum (x_i / d)^2 <= r^2 (both friction coefficients equal: condim 3), Newton on the multiplier
+__device__ __forceinline__ bool qcqp2_dev(float a11, float a12, float a22, float b1, float b2, float d, float r, float* x1, float* x2) {
+  b1 *= d; b2 *= d; a11 *= d * d; a22 *= d * d; a12 *= d * d;
+  float la = 0.f, v1 = 0.f, v2 = 0.f;
+  const float r2 = r * r;
+  for (int it = 0; it < 20; it++) {
+    const float det = (a11 + la) * (a22 + la) - a12 * a12;
+    if (det < 1e-10f) { v1 = v2 = 0.f; break; }
+    const float di = 1.f / det, P11 = (a22 + la) * di, P22 = (a11 + la) * di, P12 = -a12 * di;
+    v1 = -P11 * b1 - P12 * b2; v2 = -P12 * b1 - P22 * b2;
+    const float val = v1 * v1 + v2 * v2 - r2;
+    if (val < 1e-10f) break;
+    const float deriv = -2.f * (P11 * v1 * v1 + 2.f * P12 * v1 * v2 + P22 * v2 * v2);
+    const float delta = -val / deriv;
+    if (delta < 1e-10f) break;
+    la += delta;
+  }
+  *x1 = v1 * d; *x2 = v2 * d;
+  return la != 0.f;
+}
+
 // Height of world point p above ground entry pl along the local surface normal, and that normal.  Plane: n . p - offset.
 // Heightfield (MuJoCo hfield semantics: nrow x ncol samples over [-rx, rx] x [-ry, ry] of the geom frame, elevation = data *
 // size z): the plane of the grid triangle under p (cells split along the diagonal (c, r) - (c + 1, r + 1)); nothing outside
@@ -1276,7 +1308,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
     // ---- sensors of this (pre-integration) state; they are next iteration's link data (mj_step lag)
     {
       const v3 linvel = add3(cv.l, cross(cv.r, sub3(xi, com)));
-      if (FUSED && !last && (nfull || A.sub_links)) {      // the next before_step's links row and drag (xf is consumed above, in this step's F);
+      if (FUSED && !last && (nfull || (A.sub_links && !(A.n_it_total > 0 && nit >= A.n_it_total)))) {      // the next before_step's links row and drag (xf is consumed above, in this step's F);
         const int4 ci2 = BTABI(blo, 8);                     // a sub-step that writes no row keeps the drag force it has
         emit_links_and_drag(M, A, env, nit, isb, false, ci2.z, ci2.w, xp, xq, xi, linvel, cv.r, xf);
       }
@@ -1708,7 +1740,8 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       const int e_p0 = nlim + crs * ncg;            // first row of the pair contacts: their fork parts are rows e - e_p0 of YF
       const bool hasp = PAIRS && M.npair != 0 && ncon > ncg; // some pair contact is active in this env (uniform)
       // an env with an active pair contact (rare) takes the HBM path: the register path then carries no fork code at all
-      if (nefc <= LL.na && !hasp) {
+      constexpr bool ELLPGS = ELL && !NEWTON;          // PGS with elliptic cones: block updates on the explicit matrix, in the HBM copy of the row code only
+      if (!ELLPGS && nefc <= LL.na && !hasp && M.noslip_iterations == 0) {
         constexpr bool small = true;
         float* const YC = YJ;
         float* const EP = EPL;
@@ -1829,6 +1862,12 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   (void)cons;
   if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : nullptr;
   return nullptr;
+#elif defined(FMJ_DEV_PGSOPT_ONLY)      // development build: the one-env constraint kernels of the PGS options (elliptic cone, noslip)
+  if (dual) return nullptr;
+  if (cons == 9) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true, false, true, true>;
+  if (cons == 8) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true, true>;
+  if (cons == 1) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
+  return nullptr;
 #elif defined(FMJ_DEV_CONS2_ONLY)      // development build: only the two-env constraint kernel and its one-env fallback (compile time)
   if (dual == 5) return fused ? (void*)fmj_step_cons2_kernel<true, FMJ_TU_MAXD> : (void*)fmj_step_cons2_kernel<false, FMJ_TU_MAXD>;
   if (cons == 1 && dual == 0) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true>;
@@ -1842,6 +1881,8 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
   if (dual == 2) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 4> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 4>;
   if (dual == 4) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 2> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 2>;
   if (dual == 3) return fused ? (void*)fmj_step_dual2_kernel<true, FMJ_TU_MAXD, 3> : (void*)fmj_step_dual2_kernel<false, FMJ_TU_MAXD, 3>;
+  if (cons == 9) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true, false, true, true>;
+  if (cons == 8) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, false, true, true>;
   if (cons == 7) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, true, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, true, true, true>;
   if (cons == 6) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true, true>;
   if (cons == 5) return fused ? (void*)fmj_step_kernel<true, FMJ_TU_MAXD, true, false, true, true> : (void*)fmj_step_kernel<false, FMJ_TU_MAXD, true, false, true, true>;
@@ -1858,8 +1899,7 @@ extern "C" __attribute__((visibility("hidden"))) void* FMJ_CAT(fmj_tu_kernel_, F
 // standalone operators (same arithmetic as the fused loop; one wave per env)
 
 // SwimmingHandler.step (reference drag.pyx:389-411): lane = swimming link
-__global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const StepArgs A) {
-  const int env = blockIdx.x;
+__device__ __forceinline__ void drag_rows_of_env(const DevModel& M, const StepArgs& A, const int env) {
   for (int s = threadIdx.x; s < M.ns; s += 64) {
     const float4 s0 = STAB(s, 0), s1 = STAB(s, 1), s2 = STAB(s, 2);
     const int li = __float_as_int(s2.y), xi = __float_as_int(s2.z), body = __float_as_int(s2.w);
@@ -1888,6 +1928,7 @@ __global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const St
     }
   }
 }
+__global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const StepArgs A) { drag_rows_of_env(M, A, blockIdx.x); }
 
 // drag_forces (reference drag.pyx:152-268) of one link in every env: thread = env, rows addressed by an env stride
 __global__ void __launch_bounds__(256) fmj_drag_link_kernel(const int n_envs, const float* links_row, const long long links_stride,
@@ -1911,10 +1952,9 @@ __global__ void __launch_bounds__(256) fmj_drag_link_kernel(const int n_envs, co
 }
 
 // physics2data (reference physics.py:527-545): lane = link row, then lane = joint row
-__global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, const StepArgs A, const int links_only,
-                                                               const int* links_body, const int* joints_dof) {
-  const int env = blockIdx.x, nb = M.nbody;
-  if (A.status[env] & FMJ_WARN_FREEZE) return;         // a frozen env writes no rows (include/fmj.h)
+__device__ __forceinline__ void physics2data_rows_of_env(const DevModel& M, const StepArgs& A, const int env, const int links_only,
+                                                         const int* links_body, const int* joints_dof) {
+  const int nb = M.nbody;
   const float* sd = A.sensordata + (size_t)env * M.nsensordata;
   for (int i = threadIdx.x; i < M.n_links; i += 64) {
     const int b = links_body[i];
@@ -1943,6 +1983,33 @@ __global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, 
     for (int a = 0; a < act.y; a++) t += sa[__float_as_int(ATAB(act.x + a, 2).x)] * A.inv_torques;
     row[FMJ_JOINT_TORQUE] = t;
     row[FMJ_JOINT_LIMIT_FORCE] = sd[6 * (nb - 1) + 3 * act.z + 2] * A.inv_torques;
+  }
+}
+__global__ void __launch_bounds__(64) fmj_physics2data_kernel(const DevModel M, const StepArgs A, const int links_only,
+                                                               const int* links_body, const int* joints_dof) {
+  if (A.status[blockIdx.x] & FMJ_WARN_FREEZE) return;         // a frozen env writes no rows (include/fmj.h)
+  physics2data_rows_of_env(M, A, blockIdx.x, links_only, links_body, joints_dof);
+}
+
+// ExperimentTask.before_step up to the host callbacks, in ONE launch (fmj_before_step): physics2data rows, cycontacts2data rows, then the
+// swimming callback's drag from the links row just written (same wave: a barrier orders the stores and the loads) - the operators
+// above, called one after the other, bit for bit.  flags: FMJ_BEFORE_*.
+__global__ void __launch_bounds__(64) fmj_before_step_kernel(const DevModel M, const StepArgs A, const int flags, const int* links_body,
+                                                              const int* joints_dof, const int n_rows, const int* geom_sensor,
+                                                              const int n_pairs, const int* pairs) {
+  const int env = blockIdx.x;
+  if (A.status[env] & FMJ_WARN_FREEZE) return;
+  if (flags & FMJ_BEFORE_ROWS) physics2data_rows_of_env(M, A, env, (flags & FMJ_BEFORE_LINKS_ONLY) ? 1 : 0, links_body, joints_dof);
+  if ((flags & FMJ_BEFORE_CONTACTS) && !(flags & FMJ_BEFORE_LINKS_ONLY)) {
+    const int nc = A.ncon[env];
+    const float* C = A.contact + (size_t)env * M.max_contacts * 16;
+    for (int row = threadIdx.x; row < n_rows; row += 64)
+      contact_row(C, nc, row, geom_sensor, n_pairs, pairs, A.inv_newtons, A.inv_meters, A.contacts_rows + ((size_t)env * n_rows + row) * FMJ_CONTACT_SIZE);
+  }
+  if (flags & FMJ_BEFORE_DRAG) {
+    __threadfence_block();
+    __syncthreads();
+    drag_rows_of_env(M, A, env);
   }
 }
 
@@ -1986,7 +2053,7 @@ void* fmj_tu_kernel_20(int, int, int); void* fmj_tu_kernel_24(int, int, int); vo
 void* fmj_tu_kernel_36(int, int, int); void* fmj_tu_kernel_40(int, int, int); void* fmj_tu_kernel_44(int, int, int); void* fmj_tu_kernel_48(int, int, int);
 void* fmj_tu_kernel_52(int, int, int); void* fmj_tu_kernel_56(int, int, int); void* fmj_tu_kernel_60(int, int, int); void* fmj_tu_kernel_64(int, int, int);
 }
-static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes), 7 Newton / CG + explicit pairs (+ meshes)
+static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      // cons: 0 none, 1 limits / ground contacts, 2 + explicit pairs (and meshes), 3 Newton / CG solver, 4 + meshes only, 5 Newton / CG + meshes, 6 Newton / CG + elliptic cone (+ meshes), 7 Newton / CG + explicit pairs (+ meshes), 8 PGS + elliptic cone (+ meshes), 9 PGS + elliptic cone + explicit pairs
   void* k;
   switch (rs) {
     case 4: k = fmj_tu_kernel_4(fused, cons, dual); break;
@@ -2009,7 +2076,8 @@ static step_kernel_t tu_kernel(int rs, bool fused, int cons, int dual) {      //
   return (step_kernel_t)k;
 }
 static step_kernel_t pick_kernel(const fmj_ctx* c, bool fused) {
-  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.cone == FMJ_CONE_ELLIPTIC ? 6 : (c->dm.npair > 0 ? 7 : (c->dm.any_mesh ? 5 : 3))) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1)));
+  const int cons = !c->dm.cons ? 0 : (c->dm.solver != FMJ_SOLVER_PGS ? (c->dm.cone == FMJ_CONE_ELLIPTIC ? 6 : (c->dm.npair > 0 ? 7 : (c->dm.any_mesh ? 5 : 3)))
+                                      : (c->dm.cone == FMJ_CONE_ELLIPTIC ? (c->dm.npair > 0 ? 9 : 8) : (c->dm.npair > 0 ? 2 : (c->dm.any_mesh ? 4 : 1))));
   return tu_kernel(c->dm.rs, fused, cons, 0);
 }
 static int launch_step(fmj_ctx* c, bool fused, const StepArgs& A, void* stream) {
@@ -2116,9 +2184,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
   if (cons && m->solver != FMJ_SOLVER_PGS && m->solver != FMJ_SOLVER_NEWTON && m->solver != FMJ_SOLVER_CG) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: solver must be FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON");
-  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path covers limits and ground contacts: no explicit pairs");
   if (cons && m->cone != FMJ_CONE_PYRAMIDAL && m->cone != FMJ_CONE_ELLIPTIC) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: cone must be FMJ_CONE_PYRAMIDAL or FMJ_CONE_ELLIPTIC");
-  if (cons && m->cone == FMJ_CONE_ELLIPTIC && m->solver == FMJ_SOLVER_PGS) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: the elliptic friction cone of the HIP path needs solver = Newton or CG: its PGS kernel solves scalar (pyramid) rows, one per lane; MuJoCo's elliptic PGS (ray update + friction QCQP per contact) is in the oracle only");
   // Pyramid rows carry R = 2 mu^2 R0: below mu ~ 1e-3 (the reference's arena has friction 0, mjcf.py:1202, so a contact's friction is
   // its link's - 1e-5 after MuJoCo's clamp when the link has none) a contact force is a residual too small for an fp32 primal
   // iteration (see fmj_cons_rows.inc on the friction-0 pairs).  Such a model is solved on the dual problem throughout: the PGS
@@ -2131,7 +2197,10 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     for (int g = 0; g < m->ngeom; g++)
       if (m->geom_type[g] != FMJ_GEOM_PLANE && m->geom_type[g] != FMJ_GEOM_HFIELD && std::max(gmu, m->geom_friction[3 * g]) * isq < 1e-3) dual_instead = true;
   }
-  if (cons && m->noslip_iterations > 0) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: noslip_iterations > 0: MuJoCo's noslip post-pass (PGS on the friction rows without regularisation) is not implemented; run with noslip_iterations = 0 (the reference's default, mjcf.py:1392-1397)");
+  // The noslip post-pass works on the dual matrices, which the primal solvers never form; explicit pairs under the elliptic cone have the
+  // dual block update only (fmj_cons_rows.inc (8c)).  Such a model requested with Newton / CG is solved on the dual problem as well.
+  if (cons && m->solver != FMJ_SOLVER_PGS && (m->noslip_iterations > 0 || (m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0))) dual_instead = true;
+  if (m->noslip_iterations < 0 || !(m->noslip_tolerance >= 0)) return set_err(FMJ_ERR_ARG, "fmj_create: noslip_iterations / noslip_tolerance must not be negative");
   if (m->integrator != FMJ_INT_EULER && m->integrator != FMJ_INT_IMPLICITFAST)
     return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: integrator must be FMJ_INT_EULER or FMJ_INT_IMPLICITFAST (RK4 is four forward passes per step; implicit keeps the Coriolis derivatives, a non-symmetric matrix outside this path's tree-sparse factorisation)");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
@@ -2317,6 +2386,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   D.implicitfast = m->integrator == FMJ_INT_IMPLICITFAST;
   D.solver_iterations = dual_instead ? 10 * m->solver_iterations : m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.cone = cons ? m->cone : FMJ_CONE_PYRAMIDAL;
+  D.noslip_iterations = cons ? m->noslip_iterations : 0; D.noslip_tolerance = (float)m->noslip_tolerance;
   D.solver = (cons && !dual_instead) ? m->solver : FMJ_SOLVER_PGS; D.ls_iterations = m->ls_iterations > 0 ? m->ls_iterations : 50;
   D.ls_tolerance = (float)(m->ls_tolerance > 0 ? m->ls_tolerance : 0.01);
   D.impratio_isqrt = (float)(1.0 / sqrt(m->impratio > 0 ? m->impratio : 1.0));
@@ -2424,7 +2494,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     D.dual_ok = !cons && halves_ok;
     // the two-env constraint kernel covers what BASELINE configs[3] needs: limits + ground contacts of sphere / capsule / box / cylinder
     // geoms on ONE ground geom, pyramidal cone, PGS; everything else (pairs, meshes, Newton / CG, the elliptic cone) keeps the one-env kernel
-    D.cons2_ok = cons && halves_ok && D.rs <= FMJ_MAXD && m->solver == FMJ_SOLVER_PGS && !dual_instead && m->cone == FMJ_CONE_PYRAMIDAL && m->npair == 0 &&
+    D.cons2_ok = cons && halves_ok && D.rs <= FMJ_MAXD && m->solver == FMJ_SOLVER_PGS && !dual_instead && m->cone == FMJ_CONE_PYRAMIDAL && m->noslip_iterations == 0 && m->npair == 0 &&
                  !any_mesh && nplane <= 1 && m->ngeom <= 32;
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
     for (int t = 0; t < 3; t++) D.dual_taddm[t] = t < t0 ? (float)(mtot + m->dof_armature[t]) : 1.0f;
@@ -2755,7 +2825,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   if (a->controller == 1 && (!a->wave.amplitude || !a->wave.phase_lag || !a->wave.env_phase)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: wave controller arrays missing");
   if (a->controller != 0 && a->controller != 1) return set_err(FMJ_ERR_ARG, "fmj_step_fused: unknown controller");
   A.integrate = 1;
-  A.substeps = a->substeps > 1 ? a->substeps : 1; A.sub_links = (A.substeps > 1 && a->substep_links) ? 1 : 0;
+  A.substeps = a->substeps > 1 ? a->substeps : 1; A.sub_links = (A.substeps > 1 && a->substep_links) ? 1 : 0; A.n_it_total = a->n_iterations > 0 ? a->n_iterations : 0;
   if ((long long)a->n_steps * A.substeps > 0x7fffffffLL) return set_err(FMJ_ERR_ARG, "fmj_step_fused: n_steps * substeps overflows");
   A.n_steps = a->n_steps * A.substeps; A.iteration0 = a->iteration0; A.buffer_size = a->buffer_size; A.do_readout = a->do_readout;
   A.do_drag = a->do_drag; A.controller = a->controller; A.ctrl_step_stride = a->ctrl_step_stride;
@@ -2810,6 +2880,25 @@ int fmj_physics2data(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const 
   HIP_TRY(hipSetDevice(c->device));
   if (!c->d_links_body || !c->d_joints_dof) { int rc2 = sync_readout_maps(c); if (rc2) return rc2; }
   hipLaunchKernelGGL(fmj_physics2data_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)links_only, (const int*)c->d_links_body, (const int*)c->d_joints_dof);
+  HIP_TRY(hipGetLastError());
+  return FMJ_OK;
+}
+
+int fmj_before_step(fmj_ctx* c, const fmj_data* d, const fmj_rows* rows, const fmj_water* water, const fmj_units* units, int32_t flags,
+                    float* xfrc_applied, void* stream) {
+  if (!c || !d || !rows || !units) return set_err(FMJ_ERR_ARG, "fmj_before_step: NULL argument");
+  const bool want_rows = flags & FMJ_BEFORE_ROWS, links_only = flags & FMJ_BEFORE_LINKS_ONLY, want_con = (flags & FMJ_BEFORE_CONTACTS) && !links_only, want_drag = flags & FMJ_BEFORE_DRAG;
+  if (want_rows && (!rows->links || (!links_only && !rows->joints))) return set_err(FMJ_ERR_ARG, "fmj_before_step: links / joints rows missing");
+  if (want_con && (!rows->contacts || !d->contact || !d->ncon || !c->d_geom_sensor)) return set_err(FMJ_ERR_ARG, "fmj_before_step: contact rows need rows->contacts, the contact list and fmj_set_contact_maps");
+  if (want_drag && (!water || !rows->links || !rows->xfrc || c->dm.ns == 0)) return set_err(FMJ_ERR_ARG, "fmj_before_step: drag needs water, links and xfrc rows and fmj_set_swimming");
+  StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
+  A.links = rows->links; A.joints = rows->joints; A.xfrc = rows->xfrc; A.contacts_rows = rows->contacts; A.xfrc_applied_out = xfrc_applied;
+  fill_units(&A, units);
+  if (water) fill_water(&A, water);
+  HIP_TRY(hipSetDevice(c->device));
+  if (!c->d_links_body || !c->d_joints_dof) { int rc2 = sync_readout_maps(c); if (rc2) return rc2; }
+  hipLaunchKernelGGL(fmj_before_step_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, A, (int)flags, (const int*)c->d_links_body,
+                     (const int*)c->d_joints_dof, c->n_contact_rows, (const int*)c->d_geom_sensor, c->n_pairs, (const int*)c->d_pairs);
   HIP_TRY(hipGetLastError());
   return FMJ_OK;
 }

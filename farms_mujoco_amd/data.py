@@ -51,6 +51,22 @@ class SensorArray:
         self.names = list(names)
         self.array = array
 
+    @property
+    def array(self):
+        return self._array
+
+    @array.setter
+    def array(self, value):
+        self._array = value
+        self._base = None
+
+    def row_ptr(self, index):
+        """Device address of ring row ``index`` (= ``array[index].data_ptr()`` without building a view: the per-step host path)."""
+        if self._base is None:
+            a = self._array
+            self._base = (a.data_ptr(), a.stride(0)*a.element_size())
+        return self._base[0] + index*self._base[1]
+
 
 class AnimatData:
     def __init__(self, timestep, buffer_size, n_envs, links, joints, xfrc=None, contacts=(), device='cuda:0'):

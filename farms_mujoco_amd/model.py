@@ -22,7 +22,7 @@ import numpy as np
 
 JNT_FREE, JNT_BALL, JNT_SLIDE, JNT_HINGE = 0, 1, 2, 3
 GEOM_PLANE, GEOM_HFIELD, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER, GEOM_BOX, GEOM_MESH = 0, 1, 2, 3, 5, 6, 7
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 DEFAULT_SOLREF = (0.02, 1.0)
 DEFAULT_SOLIMP = (0.9, 0.95, 0.001, 0.5, 2.0)

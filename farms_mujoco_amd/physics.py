@@ -30,6 +30,15 @@ def _stream_ptr(device):
     return ctypes.c_void_p(torch.cuda.current_stream(device).cuda_stream)
 
 
+class _MjData(SimpleNamespace):
+    """``physics.data``: rebinding a field (``data.qpos = tensor``) is seen by the cached pointer struct of the per-step host path;
+    in-place writes (``data.qpos[:] = ...``) never move a tensor."""
+
+    def __setattr__(self, name, value):
+        object.__setattr__(self, '_cdata_cache', None)
+        object.__setattr__(self, name, value)
+
+
 class BatchedPhysics:
     """Device-resident mjData for ``n_envs`` copies of one model + the HIP step context."""
 
@@ -52,7 +61,7 @@ class BatchedPhysics:
         assert lay.nsensordata == model.nsensordata
         n, m, dev = self.n_envs, model, self.device
         z = lambda *s, dtype=torch.float32: torch.zeros(*s, dtype=dtype, device=dev)
-        self.data = SimpleNamespace(
+        self.data = _MjData(
             qpos=z(n, m.nq), qvel=z(n, m.nv), ctrl=z(n, m.nu), qpos_spring=z(n, m.nq),
             xfrc_applied=z(n, m.nbody, 6), xpos=z(n, m.nbody, 3), xquat=z(n, m.nbody, 4), xipos=z(n, m.nbody, 3),
             sensordata=z(n, m.nsensordata), qacc=z(n, m.nv), time=z(n), status=z(n, dtype=torch.int32))
@@ -71,8 +80,10 @@ class BatchedPhysics:
         self.solver_requested, self.solver_effective, self.solver_budget = names[rq.value], names[ef.value], it.value
         if rq.value != ef.value:
             import warnings
-            warnings.warn(f'solver={self.solver_requested!r} was requested, but some ground contact has friction / sqrt(impratio) < 1e-3 (rows an fp32 '
-                          f'primal iteration cannot resolve): the model is solved on the dual problem instead - {self.solver_effective} to the '
+            why = ('the noslip post-pass works on the dual matrices, which a primal solver never forms' if int(getattr(model, 'noslip_iterations', 0)) > 0 else
+                   'explicit pairs under the elliptic cone have the dual block update only' if (int(getattr(model, 'cone', 0)) == 1 and int(getattr(model, 'npair', 0)) > 0) else
+                   'some ground contact has friction / sqrt(impratio) < 1e-3 (rows an fp32 primal iteration cannot resolve)')
+            warnings.warn(f'solver={self.solver_requested!r} was requested, but {why}: the model is solved on the dual problem instead - {self.solver_effective} to the '
                           f'solver tolerance, up to {self.solver_budget} sweeps per step (same minimiser; include/fmj.h: fmj_solver_info)', stacklevel=2)
         self.links_body = np.arange(1, m.nbody, dtype=np.int32)
         self.joints_jnt = np.nonzero(m.jnt_type != JNT_FREE)[0].astype(np.int32)
@@ -87,6 +98,21 @@ class BatchedPhysics:
     # ---- marshalling ----------------------------------------------------------------------------
     def _cdata(self, ctrl: Optional[torch.Tensor] = None, use_xfrc: bool = True) -> _lib.CData:
         d = self.data
+        cached = getattr(d, '_cdata_cache', None)
+        if cached is not None:                  # a private copy: callers edit single fields (ctrl tapes)
+            c = _lib.CData.from_buffer_copy(cached)
+            if ctrl is not None:
+                c.ctrl = ctrl.data_ptr()
+            if not use_xfrc:
+                c.xfrc_applied = None
+            return c
+        c = self._cdata_build()
+        object.__setattr__(d, '_cdata_cache', _lib.CData.from_buffer_copy(c))
+        return self._cdata(ctrl, use_xfrc)
+
+    def _cdata_build(self) -> _lib.CData:
+        d = self.data
+        ctrl, use_xfrc = None, True
         c = _lib.CData()
         c.qpos, c.qvel = d.qpos.data_ptr(), d.qvel.data_ptr()
         c.ctrl = (d.ctrl if ctrl is None else ctrl).data_ptr()

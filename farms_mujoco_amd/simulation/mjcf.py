@@ -50,9 +50,10 @@ def check_supported_options(simulation_options, compile_only=False):
     reason (and again by ``fmj_create``):
       integrator  Euler (with MuJoCo's implicit joint damping) and implicitfast.  RK4 is four forward passes per step; ``implicit``
                   keeps the Coriolis derivatives, a non-symmetric matrix outside the tree-sparse L'DL of this path.
-      solver/cone PGS with the pyramidal cone; Newton / CG with the pyramidal or the elliptic cone.  PGS with the elliptic cone (MuJoCo's
-                  ray update + friction QCQP per contact) exists in the oracle only: the device PGS solves scalar rows, one per lane.
-      noslip      MuJoCo's post-pass on the friction rows without regularisation is not implemented (oracle and device)."""
+      solver/cone PGS, CG or Newton with the pyramidal or the elliptic cone (round 5: MuJoCo's elliptic PGS - ray update + friction QCQP per
+                  contact - on the device too, also on models with explicit pairs).
+      noslip      MuJoCo's post-pass on the friction rows without regularisation: oracle and device (round 5); requested with Newton / CG
+                  the device solves the step on the dual problem (fmj_solver_info says so)."""
     if simulation_options is None:
         return
     for name, supported, why in (
@@ -62,12 +63,8 @@ def check_supported_options(simulation_options, compile_only=False):
         value = getattr(simulation_options, name, None)
         if value is not None and str(value).lower() not in supported:
             raise NotImplementedError(f'simulation_options.{name}={value!r}: the HIP step implements {" / ".join(supported)} only' + (f' ({why})' if why else ''))
-    if str(getattr(simulation_options, 'cone', 'pyramidal')).lower() == 'elliptic' and str(getattr(simulation_options, 'solver', 'PGS')).lower() == 'pgs':
-        raise NotImplementedError("simulation_options.cone='elliptic' needs solver='Newton' or 'CG' on the HIP path: its PGS kernel solves scalar (pyramid) rows, "
-                                  "one per lane; MuJoCo's elliptic PGS (ray update + friction QCQP per contact) is in the oracle only")
-    if not compile_only and int(getattr(simulation_options, 'noslip_iterations', 0) or 0) > 0:     # the compiler still forwards it (MJCF export)
-        raise NotImplementedError('simulation_options.noslip_iterations > 0: MuJoCo\'s noslip post-pass (PGS on the friction rows without regularisation) is '
-                                  'not implemented in the oracle or on the device; run with noslip_iterations = 0 (the reference\'s own default, mjcf.py:1392-1397)')
+    if int(getattr(simulation_options, 'noslip_iterations', 0) or 0) < 0:
+        raise ValueError('simulation_options.noslip_iterations must not be negative')
 
 
 def sdf2model(sdf: ModelSDF, **kwargs) -> Model:

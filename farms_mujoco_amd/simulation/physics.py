@@ -73,17 +73,28 @@ def get_physics2data_maps(physics, sensor_data, sensor_maps):
     return sensor_maps
 
 
-def physics2data(physics, iteration, data, maps, units, links_only=False):
-    """Sensors data collection for every env (reference physics.py:527-545) -> C-ABI fmj_physics2data."""
+def physics2data(physics, iteration, data, maps, units, links_only=False, swimming=None):
+    """Sensors data collection for every env (reference physics.py:527-545) in ONE launch (C-ABI fmj_before_step): links and joints
+    rows, the contact rows of ``cycontacts2data`` when the data has contact sensors, and - ``swimming`` = the SwimmingHandler of a
+    swimming callback that comes first among the task's callbacks - its drag on the links row just written (reference
+    task.py:176-182: sensors, then the callbacks in order)."""
     rows = _lib.CRows()
-    rows.links = data.sensors.links.array[iteration].data_ptr()
-    rows.joints = data.sensors.joints.array[iteration].data_ptr()
-    c = physics._cdata()
-    u = units.as_c()
-    _lib.check(physics._lib.fmj_physics2data(physics._ctx, ctypes.byref(c), ctypes.byref(rows), ctypes.byref(u),
-                                             int(links_only),
-                                             ctypes.c_void_p(torch.cuda.current_stream(physics.device).cuda_stream)))
+    rows.links = data.sensors.links.row_ptr(iteration)
+    rows.joints = data.sensors.joints.row_ptr(iteration)
+    flags = _lib.BEFORE_ROWS | (_lib.BEFORE_LINKS_ONLY if links_only else 0)
     if not links_only and data.sensors.contacts.names:
-        from ..sensors.sensors import cycontacts2data
-        cycontacts2data(physics=physics, iteration=iteration, data=data.sensors.contacts,
-                        geompair2data=maps['sensors'].get('geompair2data', {}), meters=units.meters, newtons=units.newtons)
+        rows.contacts = data.sensors.contacts.row_ptr(iteration)
+        flags |= _lib.BEFORE_CONTACTS
+    water, xa = None, None
+    if swimming is not None and swimming.drag:
+        rows.xfrc = swimming.xfrc.row_ptr(iteration)
+        cwater = swimming.water.as_c(use_buoyancy=swimming.buoyancy)      # (kept alive until the call returns)
+        water = ctypes.byref(cwater)
+        xa = physics.data.xfrc_applied.data_ptr()
+        flags |= _lib.BEFORE_DRAG
+    c = physics._cdata()
+    u = getattr(units, '_c_cache', None)
+    if u is None:
+        u = units._c_cache = units.as_c()       # (SimulationUnitScaling is a set of constants for the life of a task)
+    _lib.check(physics._lib.fmj_before_step(physics._ctx, ctypes.byref(c), ctypes.byref(rows), water, ctypes.byref(u), flags,
+                                            ctypes.c_void_p(xa), ctypes.c_void_p(torch.cuda.current_stream(physics.device).cuda_stream)))

@@ -91,10 +91,40 @@ class Simulation:
 
     # ---- stepping ---------------------------------------------------------------------------------------
     def _env_step(self):
-        """Environment.step(action=None): before_step -> physics.step -> after_step."""
-        self.task.before_step(None, self.physics)
-        self.physics.step(1)
-        self.task.after_step(self.physics)
+        """Environment.step(action=None): before_step -> physics.step -> after_step.  Two launches when the task's
+        callbacks run on the host: the sensors' (+ the swimming callback's drag, fmj_before_step) and the step's - which also
+        evaluates a device controller (task.controller_in_step) -; round 4 took four and a handful of torch kernels for the ctrl write."""
+        task = self.task
+        task.before_step(None, self.physics)
+        if task.controller_in_step() and task.sim_iteration % task.substeps == 0:
+            self._step_with_controller()
+        else:
+            self.physics.step(1)
+        task.after_step(self.physics)
+
+    def _step_with_controller(self):
+        """One mj_step whose launch evaluates the device controller first (fmj_step_fused: one step, no rows, no drag - before_step
+        wrote them; xfrc_applied and qpos_spring are read from physics.data as fmj_step does)."""
+        task, phys = self.task, self.physics
+        a = getattr(self, '_step_args', None)
+        if a is None:
+            a = self._step_args = _lib.CFusedArgs()
+            a.n_steps, a.buffer_size, a.substeps = 1, task.buffer_size, 1
+            a.units = task.units.as_c()
+        a.iteration0 = task.iteration
+        c = task._controller
+        cd = phys._cdata()
+        if getattr(c, 'tape', False):
+            tape = c.ctrl_tape(1)
+            a.controller, a.ctrl_step_stride = 0, tape.stride(0)
+            cd.ctrl = tape.data_ptr()
+        else:
+            a.controller = 1
+            a.wave.amplitude, a.wave.phase_lag, a.wave.env_phase = c.amplitude.data_ptr(), c.phase_lag.data_ptr(), c.env_phase.data_ptr()
+            a.wave.frequency = c.frequency
+            a.ctrl_out = phys.data.ctrl.data_ptr()
+        _lib.check(phys._lib.fmj_step_fused(phys._ctx, ctypes.byref(cd), ctypes.byref(a),
+                                            ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
 
     def step_fused(self, n_steps: int):
         """Run ``n_steps`` full iterations (``substeps`` physics steps each) inside ONE launch (fmj_step_fused): ring-buffer
@@ -108,6 +138,7 @@ class Simulation:
         a = _lib.CFusedArgs()
         a.n_steps, a.iteration0, a.buffer_size = n_steps, task.sim_iteration//task.substeps, task.buffer_size
         a.substeps, a.substep_links = task.substeps, int(task.substeps_links)
+        a.n_iterations = task.n_iterations if task.n_iterations < (1 << 30) else 0
         a.do_readout = 1
         sens = task.data.sensors
         a.rows_base.links = sens.links.array.data_ptr()

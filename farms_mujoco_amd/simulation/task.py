@@ -18,6 +18,8 @@ def duration2nit(duration: float, timestep: float) -> int:
 class TaskCallback:
     """Task callback (reference task.py:415-446): identical hooks; ``physics`` is the batched physics."""
 
+    writes_ctrl = False      # set True in a callback that writes physics.data.ctrl itself: the step then takes ctrl from there (ExperimentTask.controller_in_step)
+
     def __init__(self, substep=False):
         self.substep = substep
 
@@ -158,25 +160,39 @@ class ExperimentTask:
                 physics.set_actuator_forcerange(limited, frange)
 
     # ---- per step -----------------------------------------------------------------------------------
-    def update_sensors(self, physics, links_only=False):
+    def update_sensors(self, physics, links_only=False, swimming=None):
         index = self.iteration % self.buffer_size
         physics2data(physics=physics, iteration=index, data=self.data, maps=self.maps, units=self.units,
-                     links_only=links_only)
+                     links_only=links_only, swimming=swimming)
+
+    def controller_in_step(self):
+        """True when the controller is evaluated by the step launch itself (Simulation._env_step -> fmj_step_fused of one step):
+        a device controller (``fusable``) in a run without sub-steps whose host callbacks do not write ``physics.data.ctrl``
+        (``TaskCallback.writes_ctrl``).  Same semantics as the fused path: actuators the controller does not drive get ctrl 0."""
+        c = self._controller
+        return (c is not None and getattr(c, 'fusable', False) and self.substeps == 1
+                and not any(getattr(cb, 'writes_ctrl', False) for cb in self._callbacks))
 
     def before_step(self, action, physics):
         """Operations before physics step (reference task.py:168-186)."""
         # the reference asserts iteration < n_iterations here; with sub-steps its own counter reaches n_iterations one sub-step
         # before the run ends (task.py:352-355) and only dm_control's reset-on-first-step, which costs the run its last
         # environment step (SURVEY Appendix C.13), keeps that assert from firing.  run() here advances all n_iterations * substeps
-        # steps, so the bound is stated on the counter that does not run ahead
+        # steps, so the bound is stated on the counter that does not run ahead - and the sub-steps the reference never executes
+        # (task.iteration == n_iterations) write no rows and call no sub-step callback: their ring index would be row 0 of a full log
         assert self.sim_iteration < self.sim_iterations
         full_step = not self.sim_iteration % self.substeps
-        if full_step or self.substeps_links:
-            self.update_sensors(physics=physics, links_only=not full_step)
-        for callback in self._callbacks:
-            if full_step or callback.substep:
+        in_run = full_step or self.iteration < self.n_iterations
+        callbacks = [cb for cb in self._callbacks if full_step or (cb.substep and in_run)]
+        sensors = (full_step or self.substeps_links) and in_run
+        # a swimming callback that comes first has its drag computed by the sensors' own launch (fmj_before_step)
+        swim = callbacks[0] if sensors and callbacks and isinstance(callbacks[0], SwimmingCallback) and callbacks[0].handler is not None else None
+        if sensors:
+            self.update_sensors(physics=physics, links_only=not full_step, swimming=None if swim is None else swim.handler)
+        for callback in callbacks:
+            if callback is not swim:
                 callback.before_step(task=self, action=action, physics=physics)
-        if full_step and self._controller is not None:
+        if full_step and self._controller is not None and not self.controller_in_step():
             self.step_control(physics)
 
     def step_control(self, physics):

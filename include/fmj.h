@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define FMJ_ABI_VERSION 5
+#define FMJ_ABI_VERSION 6
 
 /* ---- status codes ------------------------------------------------------------------------ */
 enum {
@@ -372,6 +372,19 @@ int fmj_set_contact_maps(fmj_ctx* ctx, int32_t n_contact_sensors, const int32_t*
 int fmj_contacts2data(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows, const fmj_units* units,
                       void* hip_stream);
 
+/* ExperimentTask.before_step up to the host callbacks (reference task.py:168-182) in ONE launch (ABI 6): the rows of
+ * fmj_physics2data (FMJ_BEFORE_ROWS; FMJ_BEFORE_LINKS_ONLY: the links rows alone, a sub-step), of fmj_contacts2data
+ * (FMJ_BEFORE_CONTACTS) and the swimming callback's fmj_drag on the links row just written (FMJ_BEFORE_DRAG; xfrc_applied as in
+ * fmj_drag, may be NULL) - the same device code as the three operators, the same bits, one launch instead of three: what an
+ * iteration with HOST callbacks costs is this launch plus the step (Simulation.run(fused=False)).  water may be NULL without
+ * FMJ_BEFORE_DRAG.  Frozen envs are skipped. */
+#define FMJ_BEFORE_ROWS 1
+#define FMJ_BEFORE_LINKS_ONLY 2
+#define FMJ_BEFORE_CONTACTS 4
+#define FMJ_BEFORE_DRAG 8
+int fmj_before_step(fmj_ctx* ctx, const fmj_data* d, const fmj_rows* rows, const fmj_water* water, const fmj_units* units,
+                    int32_t flags, float* xfrc_applied, void* hip_stream);
+
 /* Fused loop: for s in [0,n_steps): physics2data(row (it0+s)%buffer) -> drag -> xfrc_applied
  * -> ctrl -> mj_step, state and derived fields resident in LDS between steps
  * (ExperimentTask.before_step + Environment.step, reference task.py:168-186, simulation.py:155-156).
@@ -419,6 +432,12 @@ typedef struct fmj_fused_args {
   /* ABI 5 */
   int32_t substeps;         /* physics steps per iteration (simulation_options.num_sub_steps; task.py:61,64-66); <= 1: one */
   int32_t substep_links;    /* != 0: sub-steps write links-only rows and recompute the drag (a callback with substep=True) */
+  /* ABI 6 */
+  int32_t n_iterations;     /* the run's n_iterations (task.py:49), 0 = unknown.  With sub-steps task.iteration reaches n_iterations one
+                               sub-step before the run ends (task.py:352-355); the reference never executes that sub-step's before_step
+                               (its assert at task.py:170; dm_control's first step only resets), here it runs and writes NO rows and
+                               keeps the drag force it has - the ring index n_iterations % buffer_size would be row 0 of a full log */
+  int32_t reserved0;
 } fmj_fused_args;
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);

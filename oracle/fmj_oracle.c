@@ -1831,6 +1831,7 @@ typedef struct fused_job {
   int n_xfrc;                       /* rows per env of the xfrc array */
   double* contacts; int n_contact_rows, n_keys; const int32_t* keys;   /* contact sensor rows [buffer, n_envs, n_rows, 12] or NULL */
   int substeps, substep_links;      /* ExperimentTask.substeps (task.py:61) and substeps_links (task.py:63): see the loop below */
+  int n_iterations_total;           /* the run's n_iterations or 0 */
 } fused_job;
 
 static void* fused_worker(void* arg) {
@@ -1861,7 +1862,9 @@ static void* fused_worker(void* arg) {
     int sim_iteration = 0, iteration = J->iteration0;
     for (int s = 0; s < J->n_steps * S; s++) {
       const int full_step = (sim_iteration % S) == 0;                       /* task.py:175 */
-      const int sensors_now = full_step || J->substep_links;               /* task.py:176 */
+      /* task.py:176; a sub-step whose task.iteration has reached the run's n_iterations writes no rows and keeps its drag force
+       * (include/fmj.h, fmj_fused_args::n_iterations: the reference never executes it) */
+      const int sensors_now = full_step || (J->substep_links && !(J->n_iterations_total > 0 && iteration >= J->n_iterations_total));
       const int links_only = !full_step;
       int it = iteration, index = it % J->buffer_size;                     /* task.py:158 */
       double* lrow = tmp_links;
@@ -1916,7 +1919,8 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
                    double surface, const double* water_vel, double viscosity, double gravity, int use_buoyancy,
                    const double* units, const double* wave_amplitude, const double* wave_phase_lag,
                    const double* wave_env_phase, double wave_frequency, int n_threads,
-                   int n_xfrc, double* contacts, int n_contact_rows, int n_keys, const int32_t* keys, int substeps, int substep_links) {
+                   int n_xfrc, double* contacts, int n_contact_rows, int n_keys, const int32_t* keys, int substeps, int substep_links,
+                   int n_iterations_total) {
   if (!m || m->abi_version != FMJ_ABI_VERSION) return FMJ_ERR_ARG;
   if (n_threads < 1) n_threads = 1;
   if (n_threads > n_envs) n_threads = n_envs;
@@ -1939,7 +1943,7 @@ int fmjo_run_fused(const fmj_model* m, int n_envs, int n_steps, int iteration0, 
     J->wave_amplitude = wave_amplitude; J->wave_phase_lag = wave_phase_lag; J->wave_env_phase = wave_env_phase;
     J->wave_frequency = wave_frequency; J->meaninertia = mi;
     J->n_xfrc = n_xfrc > 0 ? n_xfrc : n_links; J->contacts = contacts; J->n_contact_rows = n_contact_rows; J->n_keys = n_keys; J->keys = keys;
-    J->substeps = substeps; J->substep_links = substeps > 1 ? substep_links : 0;
+    J->substeps = substeps; J->substep_links = substeps > 1 ? substep_links : 0; J->n_iterations_total = n_iterations_total;
     if (n_threads == 1) fused_worker(J); else pthread_create(&th[t], NULL, fused_worker, J);
   }
   if (n_threads > 1) for (int t = 0; t < n_threads; t++) pthread_join(th[t], NULL);

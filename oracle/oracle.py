@@ -231,7 +231,7 @@ def contacts_from_hip(contact16):
 def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer_size=1, do_readout=True,
               do_drag=True, controller=0, ctrl=None, ctrl_step_stride=0, wave=None, links_body=None,
               joints_jnt=None, units=(1.0, 1.0, 1.0, 1.0, 1.0), n_threads=1, n_xfrc=None, geompair2data=None,
-              n_contact_rows=0, substeps=1, substep_links=False):
+              n_contact_rows=0, substeps=1, substep_links=False, n_iterations=0):
     """The fused loop (readout -> drag -> ctrl -> mj_step) x n_steps.  ``state`` = dict(qpos, qvel, xpos, xquat,
     xipos, sensordata[, qpos_spring]) batch-first; returns new state + ring-buffer rows.  ``n_xfrc`` = rows per env of
     the xfrc array (default: one per link row); ``geompair2data`` + ``n_contact_rows`` add the contact sensor rows.
@@ -275,7 +275,7 @@ def run_fused(model, state, n_steps, swim=None, water=None, iteration0=0, buffer
                               ctypes.c_double(water['viscosity']), ctypes.c_double(water.get('gravity', -9.81)),
                               int(water['use_buoyancy']), _d(u), _d(wa), _d(wp), _d(we), ctypes.c_double(wf),
                               int(n_threads), n_xfrc, _d(contacts), int(n_contact_rows), 0 if keys is None else len(keys),
-                              _i(keys), int(substeps), int(bool(substep_links)))
+                              _i(keys), int(substeps), int(bool(substep_links)), int(n_iterations))
     assert rc == 0, rc
     return dict(qpos=qpos, qvel=qvel, xpos=xpos, xquat=xquat, xipos=xipos, sensordata=sd, status=status,
                 links=links, joints=joints, xfrc=xfrc, contacts=contacts)

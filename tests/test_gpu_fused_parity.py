@@ -407,7 +407,7 @@ def test_fused_substeps_match_oracle(oracle, substeps, sub_links):
     st = _oracle_initial_state(oracle, sim, m)
     swim, water = _swim_water(sim)
     c = sim.task._controller
-    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=T, controller=1, substeps=substeps, substep_links=sub_links,
+    ref = oracle.run_fused(m, st, T, swim=swim, water=water, buffer_size=T, controller=1, substeps=substeps, substep_links=sub_links, n_iterations=T,
                            wave=dict(amplitude=c.amplitude.cpu().numpy(), phase_lag=c.phase_lag.cpu().numpy(),
                                      env_phase=c.env_phase.cpu().numpy(), frequency=c.frequency))
     sim.run(fused=True)
@@ -447,12 +447,17 @@ def test_fused_equals_unfused_with_substeps(oracle, substeps):
         for k in ('qpos', 'qvel', 'xpos', 'sensordata'):
             a = getattr(sim_f.physics.data, k).cpu().numpy(); b = getattr(sim_u.physics.data, k).cpu().numpy()
             assert _relerr(a, b) < 5e-4, (substeps, sub_links, k, _relerr(a, b))
-        # rows: the unfused run's LAST sub-steps wrote a links-only row into ring index T % T = 0 when a callback asked for sub-steps
-        # (the reference does: iteration has reached n_iterations by then); the fused launch stops emitting at its last step
-        lo = 1 if (sub_links and substeps > 1) else 0
+        # every row, row 0 included: the sub-steps of the last iteration whose task.iteration has reached n_iterations (the reference never
+        # executes them: its assert at task.py:170) write nothing, so the ring index n_iterations % buffer_size = 0 keeps the first
+        # full step's row (include/fmj.h: fmj_fused_args::n_iterations)
         for k in ('links', 'joints', 'xfrc'):
-            a = getattr(sim_f.task.data.sensors, k).array.cpu().numpy()[lo:]; b = getattr(sim_u.task.data.sensors, k).array.cpu().numpy()[lo:]
+            a = getattr(sim_f.task.data.sensors, k).array.cpu().numpy(); b = getattr(sim_u.task.data.sensors, k).array.cpu().numpy()
             assert _relerr(a, b) < 5e-4, (substeps, sub_links, k, _relerr(a, b))
+            assert _relerr(a[0], b[0]) < 5e-4 and np.abs(a[0]).max() > 0
+        if sub_links and substeps > 1:      # ... and that row 0 is the FIRST iteration's: its joints row was written once, by the first full step
+            q0 = sim_f.task.data.sensors.joints.array[0].cpu().numpy()[..., 0]
+            qT = sim_f.physics.data.qpos.cpu().numpy()[:, 7:]
+            assert np.abs(q0 - qT).max() > 1e-3
 
 
 def test_fused_substeps_chunked_equals_one_launch(oracle):

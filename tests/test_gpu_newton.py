@@ -199,15 +199,19 @@ def test_newton_and_cg_with_self_collision_pairs(oracle, solver):
     assert e40.max() < 2e-3 and np.median(e40) < 3e-4
 
 
-def test_elliptic_cone_refused_with_pgs_and_with_pairs():
+def test_elliptic_cone_with_newton_and_pairs_runs_on_the_dual_problem():
+    """Round 4 refused the elliptic cone with PGS and on models with explicit pairs.  Round 5: PGS has MuJoCo's block update
+    (tests/test_gpu_pgs_options.py); Newton / CG with pairs is solved on the dual problem, and says so."""
     from farms_mujoco_amd.model import salamander33, SOLVERS, CONES
     from farms_mujoco_amd.physics import BatchedPhysics
-    from farms_mujoco_amd._lib import FmjError
-    for solver, kw in (('pgs', {}), ('newton', dict(self_collisions=True))):
-        m = salamander33(contacts=True, limits=True, spawn_z=0.045, **kw)
-        m.solver = SOLVERS[solver]; m.cone = CONES['elliptic']
-        with pytest.raises(FmjError):
-            BatchedPhysics(m, 2)
+    m = salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=True)
+    m.solver = SOLVERS['newton']; m.cone = CONES['elliptic']
+    with pytest.warns(UserWarning, match='dual problem'):
+        phys = BatchedPhysics(m, 2)
+    assert phys.solver_requested == 'Newton' and phys.solver_effective == 'PGS'
+    m = salamander33(contacts=True, limits=True, spawn_z=0.045)
+    m.cone = CONES['elliptic']
+    assert BatchedPhysics(m, 2).solver_effective == 'PGS'
 
 
 @pytest.mark.parametrize('solver,impratio', [('newton', 1.0), ('cg', 1.0), ('newton', 4.0)])

@@ -21,7 +21,7 @@ class _Recorder(TaskCallback):
 
 def _task(**kw):
     t = ExperimentTask(base_link='b', n_iterations=kw.pop('n_iterations', 6), timestep=1e-3, **kw)
-    t.update_sensors = lambda physics, links_only=False: t._sensor_calls.append((t.iteration % t.buffer_size, links_only))
+    t.update_sensors = lambda physics, links_only=False, swimming=None: t._sensor_calls.append((t.iteration % t.buffer_size, links_only))
     t._sensor_calls = []
     return t
 
@@ -60,6 +60,21 @@ def test_substep_quirk_matches_reference():
     assert len(cbs.before) == 4*sub - 1
     # sensors: full rows on full steps, links_only rows on sub-steps because a callback asked for sub-steps
     assert [lo for _, lo in t._sensor_calls[:4]] == [False, True, True, False]
+
+
+def test_substeps_past_the_last_iteration_write_nothing():
+    """run() executes all n_iterations * substeps steps; the reference never executes the sub-steps whose task.iteration
+    has reached n_iterations (its assert at task.py:170).  They run here, but write no rows and call no sub-step callback: ring index
+    n_iterations % buffer_size would be row 0 of a full log."""
+    sub, n_it = 3, 4
+    cb, cbs = _Recorder(), _Recorder(substep=True)
+    t = _task(n_iterations=n_it, substeps=sub, callbacks=[cb, cbs], buffer_size=n_it)
+    for _ in range(n_it*sub):
+        t.before_step(None, _FakePhysics()); t.after_step(_FakePhysics())
+    assert t.sim_iteration == n_it*sub and t.iteration == n_it
+    assert len(cbs.before) == n_it*sub - 1 and all(it < n_it for _, it in cbs.before)
+    assert len(t._sensor_calls) == n_it*sub - 1
+    assert [i for i, lo in t._sensor_calls if i == 0] == [0, 0]            # row 0: the first full step and its first sub-step, nothing later
 
 
 def test_fusable_rules():
@@ -178,8 +193,9 @@ def test_unsupported_solver_options_are_refused():
     check_supported_options(SimulationOptions(integrator='implicitfast'))     # round 4
     check_supported_options(SimulationOptions(noslip_iterations=3), compile_only=True)      # the model compiler forwards it (MJCF export)
     check_supported_options(None)
-    for kw, word in ((dict(cone='elliptic'), 'QCQP'), (dict(cone='elliptic', solver='PGS'), 'QCQP'), (dict(integrator='RK4'), 'four forward passes'),
-                     (dict(integrator='implicit'), 'Coriolis'), (dict(solver='SOR'), 'pgs'), (dict(noslip_iterations=3), 'noslip')):
+    check_supported_options(SimulationOptions(cone='elliptic', solver='PGS'))     # round 5: MuJoCo's elliptic PGS on the device
+    check_supported_options(SimulationOptions(noslip_iterations=3))               # round 5: the noslip post-pass
+    for kw, word in ((dict(integrator='RK4'), 'four forward passes'), (dict(integrator='implicit'), 'Coriolis'), (dict(solver='SOR'), 'pgs')):
         with pytest.raises(NotImplementedError, match=word):      # a refusal says why
             check_supported_options(SimulationOptions(**kw))
 
