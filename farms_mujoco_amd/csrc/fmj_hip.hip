@@ -84,6 +84,8 @@ struct DevModel {
   const uint8_t* b_anc;       // [nbody][anc_stride] ancestor at distance 2^r (0 = world)
   const float* hf_data;       // [hf_nrow][hf_ncol] heightfield samples (one heightfield per model)
   const float4* mesh_vert;    // [nmeshvert] hull vertices of the mesh geoms, geom frame (gtab size.x / .y: first vertex, count)
+  const float4* mesh_face;    // [nmeshface] planes of their hulls (n, d: n . x <= d inside), geom frame (gtab info.w: first face, sol1.w: count): explicit pairs
+  int any_polypair;           // some explicit pair involves a box, a cylinder or a mesh (include/fmj.h, ABI 6)
   int any_mesh;
   int hf_nrow, hf_ncol;
   int npair, nfl;             // explicit geom pairs; fork rows (4 per pair contact) the LDS path provides
@@ -829,6 +831,115 @@ __device__ __forceinline__ void row_params(float sr0, float sr1, float si0, floa
   } else { K = -sr0 / fmaxf(1e-15f, dmax * dmax); B = -sr1 / fmaxf(1e-15f, dmax); }
   *R = fmaxf(1e-15f, (1.f - imp) * diag_approx / imp);
   *kimp = K * imp; *bb = B;
+}
+
+// ---- polytopes (box, cylinder, convex mesh) in explicit pairs: include/fmj.h (ABI 6), oracle poly_vertex / poly_signed / collide_pair
+__device__ __forceinline__ bool geom_is_round(int t) { return t == FMJ_GEOM_SPHERE || t == FMJ_GEOM_CAPSULE; }
+// vertex k of polytope (type, size row gs) in the geom frame
+template <class MT>
+__device__ __forceinline__ v3 poly_vertex(MT& M, int type, float4 gs, int k) {
+  if (type == FMJ_GEOM_BOX) return mk3((k & 1) ? gs.x : -gs.x, (k & 2) ? gs.y : -gs.y, (k & 4) ? gs.z : -gs.z);
+  if (type == FMJ_GEOM_CYLINDER) {          // 12 points on each rim in steps of 150 degrees, the first on +x; k < 12: the +z rim
+    float sn, cs;
+    sincospif((float)(((k % 12) * 5) % 12) * (1.0f / 6.0f), &sn, &cs);
+    return mk3(gs.x * cs, gs.x * sn, k < 12 ? gs.y : -gs.y);
+  }
+  const float4 v = ldg4(M.mesh_vert, (unsigned)(__float_as_int(gs.x) + k));
+  return mk3(v.x, v.y, v.z);
+}
+// signed distance of x (geom frame) to the polytope = max over its faces of (n . x - d), and that face's outward normal
+template <class MT>
+__device__ __forceinline__ float poly_signed(MT& M, int type, float4 gs, int face0, int nface, v3 x, v3* n) {
+  if (type == FMJ_GEOM_BOX) {
+    const float sx = fabsf(x.x) - gs.x, sy = fabsf(x.y) - gs.y, sz = fabsf(x.z) - gs.z;
+    float s = sx; *n = mk3(x.x < 0.f ? -1.f : 1.f, 0.f, 0.f);
+    if (sy > s) { s = sy; *n = mk3(0.f, x.y < 0.f ? -1.f : 1.f, 0.f); }
+    if (sz > s) { s = sz; *n = mk3(0.f, 0.f, x.z < 0.f ? -1.f : 1.f); }
+    return s;
+  }
+  if (type == FMJ_GEOM_CYLINDER) {
+    const float r = sqrtf(x.x * x.x + x.y * x.y);
+    float s = fabsf(x.z) - gs.y; *n = mk3(0.f, 0.f, x.z < 0.f ? -1.f : 1.f);
+    if (r - gs.x > s) { s = r - gs.x; *n = r > 1e-15f ? mk3(x.x / r, x.y / r, 0.f) : mk3(1.f, 0.f, 0.f); }
+    return s;
+  }
+  float s = -1e30f; *n = mk3(0.f, 0.f, 1.f);
+  for (int f = 0; f < nface; f++) {
+    const float4 pl = ldg4(M.mesh_face, (unsigned)(face0 + f));
+    const float sf = pl.x * x.x + pl.y * x.y + pl.z * x.z - pl.w;
+    if (sf > s) { s = sf; *n = mk3(pl.x, pl.y, pl.z); }
+  }
+  return s;
+}
+__device__ __forceinline__ float geom_rbound(int type, float4 gs) {
+  return type == FMJ_GEOM_SPHERE ? gs.x : type == FMJ_GEOM_CAPSULE ? gs.x + gs.y : type == FMJ_GEOM_CYLINDER ? sqrtf(gs.x * gs.x + gs.y * gs.y)
+       : type == FMJ_GEOM_BOX ? sqrtf(gs.x * gs.x + gs.y * gs.y + gs.z * gs.z) : gs.z;
+}
+// explicit pair (g1, g2) with at least one polytope: up to 4 contacts (position, normal from geom1 to geom2, distance), PO = body poses in LDS
+template <class MT>
+__device__ __forceinline__ int pair_polytope(MT& M, const float* PO, int g1, int g2, v3* cq, v3* nq, float* dq) {
+  int type[2], face0[2], nface[2], nvert[2]; float4 gs[2]; v3 pos[2]; q4 wq[2], wqc[2];
+#pragma unroll
+  for (int k = 0; k < 2; k++) {
+    const int g = k ? g2 : g1;
+    const int4 gi = GTABI(g, 0);
+    const float4 gp = GTAB(g, 2), gq = GTAB(g, 3);
+    gs[k] = GTAB(g, 1);
+    type[k] = gi.x; face0[k] = gi.w; nface[k] = __float_as_int(GTAB(g, 5).w);
+    nvert[k] = gi.x == FMJ_GEOM_BOX ? 8 : gi.x == FMJ_GEOM_CYLINDER ? 24 : gi.x == FMJ_GEOM_MESH ? __float_as_int(gs[k].y) : 0;
+    const float4 bp = *(const float4*)(PO + gi.y * 8), bq = *(const float4*)(PO + gi.y * 8 + 4);
+    const q4 bqq = {bq.x, bq.y, bq.z, bq.w}, gqq = {gq.x, gq.y, gq.z, gq.w};
+    wq[k] = qmul(bqq, gqq); wqc[k] = q4{wq[k].w, -wq[k].x, -wq[k].y, -wq[k].z};
+    pos[k] = add3(mk3(bp.x, bp.y, bp.z), qrot(bqq, mk3(gp.x, gp.y, gp.z)));
+  }
+  const v3 dc = sub3(pos[1], pos[0]);
+  if (sqrtf(dot3(dc, dc)) > geom_rbound(type[0], gs[0]) + geom_rbound(type[1], gs[1])) return 0;
+  const bool r0 = geom_is_round(type[0]), r1 = geom_is_round(type[1]);
+  int cnt = 0;
+  if (r0 != r1) {                              // polytope against sphere / capsule: the round geom's centres against the faces
+    const int rk = r0 ? 0 : 1, pk = 1 - rk;
+    const float rad = gs[rk].x, half = gs[rk].y;
+    const int ncen = type[rk] == FMJ_GEOM_CAPSULE ? 2 : 1;
+    const v3 ax = qrot(wq[rk], mk3(0.f, 0.f, 1.f));
+    for (int c = 0; c < ncen; c++) {
+      const float sgn = ncen == 2 ? (c == 0 ? 1.f : -1.f) : 0.f;
+      const v3 cw = add3(pos[rk], scl3(ax, sgn * half));
+      v3 nl;
+      const float dist = poly_signed(M, type[pk], gs[pk], face0[pk], nface[pk], qrot(wqc[pk], sub3(cw, pos[pk])), &nl) - rad;
+      if (dist < 0.f) {
+        const v3 nw = qrot(wq[pk], nl);
+        const v3 cp = sub3(cw, scl3(nw, rad + 0.5f * dist)), n12 = pk == 0 ? nw : scl3(nw, -1.f);
+#pragma unroll
+        for (int q = 0; q < 2; q++) if (cnt == q) { cq[q] = cp; nq[q] = n12; dq[q] = dist; }
+        cnt++;
+      }
+    }
+    return cnt;
+  }
+  for (int side = 0; side < 2; side++) {       // side 0: geom1's vertices in geom2; side 1: geom2's vertices in geom1
+    const int va = side, fb = 1 - side;
+    for (int k = 0; k < nvert[va]; k++) {
+      const v3 vw = add3(pos[va], qrot(wq[va], poly_vertex(M, type[va], gs[va], k)));
+      v3 nl;
+      float td = poly_signed(M, type[fb], gs[fb], face0[fb], nface[fb], qrot(wqc[fb], sub3(vw, pos[fb])), &nl);
+      if (!(td < 0.f)) continue;
+      const v3 nw = qrot(wq[fb], nl);
+      v3 tc = sub3(vw, scl3(nw, 0.5f * td)), tn = fb == 0 ? nw : scl3(nw, -1.f);
+      bool have = true;                          // insertion by depth, ties keep the earlier candidate (the rule of mesh against ground)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bool empty = q >= cnt;
+        if (have && (empty || td < dq[q])) {
+          const float sd = dq[q]; const v3 sc = cq[q], sn = nq[q];
+          dq[q] = td; cq[q] = tc; nq[q] = tn;
+          td = sd; tc = sc; tn = sn;
+          have = !empty;
+        }
+      }
+      if (cnt < 4) cnt++;
+    }
+  }
+  return cnt;
 }
 
 // ---- elliptic cone on the dual side (mj_solPGS's block update, the noslip pass): oracle cone_zone / qcqp2 / pgs_elliptic_block in fp32
@@ -1671,10 +1782,15 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       if (PAIRS && M.npair) {
         for (int p0 = 0; p0 < M.npair; p0 += 64) {
           const int pr = p0 + lane;
-          bool hit = false; v3 pos = mk3(0.f, 0.f, 0.f), nrm = mk3(0.f, 0.f, 1.f); float dist = 0.f, mu = 0.f; int g1 = 0, g2 = 0;
+          int pcnt = 0; v3 pcq[4], pnq[4]; float pdq[4]; float mu = 0.f; int g1 = 0, g2 = 0;
+#pragma unroll
+          for (int k = 0; k < 4; k++) { pcq[k] = mk3(0.f, 0.f, 0.f); pnq[k] = mk3(0.f, 0.f, 1.f); pdq[k] = 0.f; }
           if (pr < M.npair) {
             const float4 q0 = QTAB(pr, 0);
             g1 = __float_as_int(q0.x); g2 = __float_as_int(q0.y); mu = q0.z;
+            const int t1 = GTABI(g1, 0).x, t2 = GTABI(g2, 0).x;
+            if (M.any_polypair && !(geom_is_round(t1) && geom_is_round(t2))) pcnt = pair_polytope(M, PO, g1, g2, pcq, pnq, pdq);
+            else {
             v3 cen[2], ax[2]; float half[2], rad[2];
 #pragma unroll
             for (int k = 0; k < 2; k++) {
@@ -1703,25 +1819,31 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
             const v3 p1 = add3(cen[0], scl3(ax[0], sp)), p2 = add3(cen[1], scl3(ax[1], tp));
             v3 n = sub3(p2, p1);
             const float len = sqrtf(dot3(n, n));
-            dist = len - rad[0] - rad[1];
-            hit = dist < 0.f;
+            const float dist = len - rad[0] - rad[1];
             n = len < 1e-15f ? mk3(0.f, 0.f, 1.f) : scl3(n, 1.0f / len);
-            nrm = n;
-            pos = add3(p1, scl3(n, rad[0] + 0.5f * dist));
+            if (dist < 0.f) { pcnt = 1; pdq[0] = dist; pnq[0] = n; pcq[0] = add3(p1, scl3(n, rad[0] + 0.5f * dist)); }
+            }
           }
-          const unsigned long long bk = __ballot(hit);
-          const int slot = ncon + __popcll(bk & lt);
-          ncon += __popcll(bk);
-          if (hit && slot < M.max_contacts) {
-            v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
-            t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
-            t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
-            const v3 t2 = cross(nrm, t1);
-            float* ct = CT + slot * 16;
-            *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
-            *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
-            *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
-            *(float4*)(ct + 12) = make_float4(dist, mu, __int_as_float(g2 | ((GTABI(g2, 0).z + 1) << 16)), __int_as_float(g1 | ((pr + 1) << 16)));
+          int before = 0, total = 0;                  // contacts in pair order, a pair's own in its own order (like the oracle)
+#pragma unroll
+          for (int k = 0; k < 4; k++) { const unsigned long long bk = __ballot(pcnt > k); before += __popcll(bk & lt); total += __popcll(bk); }
+          const int s0 = ncon + before;
+          ncon += total;
+#pragma unroll
+          for (int k = 0; k < 4; k++) {
+            const int slot = s0 + k;
+            if (k < pcnt && slot < M.max_contacts) {
+              const v3 nrm = pnq[k], pos = pcq[k];
+              v3 t1 = (nrm.y < -0.5f || nrm.y > 0.5f) ? mk3(0.f, 0.f, 1.f) : mk3(0.f, 1.f, 0.f);
+              t1 = sub3(t1, scl3(nrm, dot3(t1, nrm)));
+              t1 = scl3(t1, 1.0f / sqrtf(dot3(t1, t1)));
+              const v3 t2 = cross(nrm, t1);
+              float* ct = CT + slot * 16;
+              *(float4*)(ct) = make_float4(pos.x, pos.y, pos.z, nrm.x);
+              *(float4*)(ct + 4) = make_float4(nrm.y, nrm.z, t1.x, t1.y);
+              *(float4*)(ct + 8) = make_float4(t1.z, t2.x, t2.y, t2.z);
+              *(float4*)(ct + 12) = make_float4(pdq[k], mu, __int_as_float(g2 | ((GTABI(g2, 0).z + 1) << 16)), __int_as_float(g1 | ((pr + 1) << 16)));
+            }
           }
         }
       }
@@ -2148,7 +2270,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   if (m->abi_version != FMJ_ABI_VERSION) return set_err(FMJ_ERR_ARG, "fmj_create: abi_version mismatch");
   const int nb = m->nbody, nv = m->nv, nq = m->nq, nu = m->nu, nj = m->njnt;
   if (nb < 2 || nb > 64 || nv < 1 || nv > 64) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: need 2 <= nbody <= 64 and 1 <= nv <= 64 (one wavefront per environment)");
-  int any_limit = 0, nplane = 0, any_box = 0, n_hfield = 0, any_mesh = 0;     // nplane counts the ground geoms: planes and the heightfield
+  int any_limit = 0, nplane = 0, any_box = 0, n_hfield = 0, any_mesh = 0, any_polypair = 0;     // nplane counts the ground geoms: planes and the heightfield
   for (int j = 0; j < nj; j++) if (m->jnt_limited[j] && m->jnt_type[j] != FMJ_JNT_FREE) any_limit = 1;
   for (int g = 0; g < m->ngeom; g++) {
     int t = m->geom_type[g];
@@ -2178,8 +2300,14 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     const int g1 = m->pair_geom1[p], g2 = m->pair_geom2[p];
     if (g1 < 0 || g1 >= m->ngeom || g2 < 0 || g2 >= m->ngeom) return set_err(FMJ_ERR_ARG, "fmj_create: pair geom out of range");
     const int t1 = m->geom_type[g1], t2 = m->geom_type[g2];
-    if ((t1 != FMJ_GEOM_SPHERE && t1 != FMJ_GEOM_CAPSULE) || (t2 != FMJ_GEOM_SPHERE && t2 != FMJ_GEOM_CAPSULE))
-      return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: explicit contact pairs need sphere / capsule geoms");
+    for (int k = 0; k < 2; k++) {
+      const int tt = k ? t2 : t1, gg = k ? g2 : g1;
+      if (tt == FMJ_GEOM_PLANE || tt == FMJ_GEOM_HFIELD) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: explicit contact pairs join two animat geoms (sphere / capsule / box / cylinder / convex mesh); the ground meets every geom already");
+      if (tt == FMJ_GEOM_BOX || tt == FMJ_GEOM_CYLINDER || tt == FMJ_GEOM_MESH) any_polypair = 1;
+      if (tt == FMJ_GEOM_MESH && (m->nmeshface < 4 || !m->mesh_face || !m->geom_faceadr || !m->geom_facenum || m->geom_facenum[gg] < 4 ||
+                                  m->geom_faceadr[gg] < 0 || m->geom_faceadr[gg] + m->geom_facenum[gg] > m->nmeshface))
+        return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: an explicit pair with a mesh geom needs the planes of its convex hull (mesh_face / geom_faceadr / geom_facenum, at least 4: a flat or collinear vertex cloud has no hull)");
+    }
     if (m->geom_bodyid[g1] == m->geom_bodyid[g2]) return set_err(FMJ_ERR_ARG, "fmj_create: a contact pair joins geoms of two bodies");
   }
   const int cons = any_limit || (nplane > 0 && m->ngeom > nplane) || m->npair > 0;
@@ -2402,7 +2530,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       int b = m->geom_bodyid[g];
       int last = -1;
       for (int a = b; a >= 1 && last < 0; a = m->body_parentid[a]) if (m->body_dofnum[a] > 0) last = m->body_dofadr[a] + m->body_dofnum[a] - 1;
-      g_info[g] = make_int4(m->geom_type[g], b, last, 0);
+      g_info[g] = make_int4(m->geom_type[g], b, last, (m->geom_type[g] == FMJ_GEOM_MESH && m->geom_faceadr && m->nmeshface > 0) ? m->geom_faceadr[g] : 0);
       g_size[g] = f4(m->geom_size[3 * g], m->geom_size[3 * g + 1], m->geom_size[3 * g + 2], m->geom_friction[3 * g]);
       if (m->geom_type[g] == FMJ_GEOM_MESH) {          // first vertex, vertex count, bounding radius about the geom origin
         double r2 = 0;
@@ -2416,6 +2544,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       g_quat[g] = f4(m->geom_quat[4 * g], m->geom_quat[4 * g + 1], m->geom_quat[4 * g + 2], m->geom_quat[4 * g + 3]);
       g_sol0[g] = f4(m->geom_solref[2 * g], m->geom_solref[2 * g + 1], m->geom_solimp[5 * g], m->geom_solimp[5 * g + 1]);
       g_sol1[g] = f4(m->geom_solimp[5 * g + 2], m->geom_solimp[5 * g + 3], m->geom_solimp[5 * g + 4], 0);
+      g_sol1[g].w = ibits((m->geom_type[g] == FMJ_GEOM_MESH && m->geom_facenum && m->nmeshface > 0) ? m->geom_facenum[g] : 0);      // hull planes (explicit pairs)
       if (m->geom_type[g] == FMJ_GEOM_PLANE) {
         // world-attached plane: normal = z axis of the geom frame, point = geom_pos
         const double* q = m->geom_quat + 4 * g; const double* p = m->geom_pos + 3 * g;
@@ -2470,6 +2599,12 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
       qtab[p * QT_STRIDE + 2] = f4(m->pair_solimp[5 * p + 2], m->pair_solimp[5 * p + 3], m->pair_solimp[5 * p + 4], 0);
     }
     UP(qtab, qtab);
+  }
+  D.any_polypair = cons ? any_polypair : 0; D.mesh_face = nullptr;
+  if (cons && any_polypair) {
+    std::vector<float4> mf(m->nmeshface > 0 ? m->nmeshface : 1, f4(0, 0, 1, 0));
+    for (int i = 0; i < m->nmeshface; i++) mf[i] = f4(m->mesh_face[4 * i], m->mesh_face[4 * i + 1], m->mesh_face[4 * i + 2], m->mesh_face[4 * i + 3]);
+    UP(mf, mesh_face);
   }
   D.any_mesh = cons ? any_mesh : 0; D.mesh_vert = nullptr;
   if (any_mesh) {

@@ -268,7 +268,8 @@ _CMODEL_FIELDS = (
         [('solver_iterations', ctypes.c_int32), ('max_contacts', ctypes.c_int32),
          ('impratio', ctypes.c_double), ('solver_tolerance', ctypes.c_double), ('meaninertia', ctypes.c_double)] +
         [('solver', ctypes.c_int32), ('cone', ctypes.c_int32), ('ls_iterations', ctypes.c_int32), ('noslip_iterations', ctypes.c_int32),
-         ('ls_tolerance', ctypes.c_double), ('noslip_tolerance', ctypes.c_double), ('integrator', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
+         ('ls_tolerance', ctypes.c_double), ('noslip_tolerance', ctypes.c_double), ('integrator', ctypes.c_int32)] +
+        [('nmeshface', ctypes.c_int32), ('mesh_face', _D), ('geom_faceadr', _I), ('geom_facenum', _I)]
 )
 SOLVERS = {'pgs': 0, 'cg': 1, 'newton': 2}          # mjtSolver (include/fmj.h FMJ_SOLVER_*)
 CONES = {'pyramidal': 0, 'elliptic': 1}            # mjtCone
@@ -283,13 +284,34 @@ class _CModel(ctypes.Structure):
 _INT_FIELDS = ('body_parentid', 'body_rootid', 'body_jntadr', 'body_dofadr', 'body_dofnum', 'jnt_type',
                'jnt_qposadr', 'jnt_dofadr', 'jnt_bodyid', 'jnt_limited', 'dof_bodyid', 'dof_jntid',
                'dof_parentid', 'dof_Madr', 'actuator_jntid', 'actuator_ctrllimited', 'actuator_forcelimited',
-               'geom_type', 'geom_bodyid', 'pair_geom1', 'pair_geom2', 'geom_vertadr', 'geom_vertnum')
+               'geom_type', 'geom_bodyid', 'pair_geom1', 'pair_geom2', 'geom_vertadr', 'geom_vertnum', 'geom_faceadr', 'geom_facenum')
 _DBL_FIELDS = ('body_pos', 'body_quat', 'body_ipos', 'body_iquat', 'body_mass', 'body_inertia', 'jnt_pos',
                'jnt_axis', 'jnt_stiffness', 'jnt_range', 'jnt_solref', 'jnt_solimp', 'jnt_margin', 'qpos0',
                'dof_armature', 'dof_damping', 'dof_invweight0', 'actuator_gain', 'actuator_bias',
                'actuator_ctrlrange', 'actuator_forcerange', 'geom_size', 'geom_pos', 'geom_quat',
                'geom_friction', 'geom_solref', 'geom_solimp', 'body_invweight0', 'pair_friction', 'pair_solref', 'pair_solimp',
-               'mesh_vert')
+               'mesh_vert', 'mesh_face')
+
+
+def hull_faces(vertices):
+    """Planes of the convex hull of ``vertices`` [n, 3]: rows (nx, ny, nz, d), outward unit normal, n . x <= d inside; coplanar
+    triangles of the hull merged into one plane.  A degenerate cloud (flat, collinear) has no faces: [0, 4]."""
+    v = np.ascontiguousarray(vertices, float).reshape(-1, 3)
+    if len(v) < 4:
+        return np.zeros((0, 4))
+    try:
+        from scipy.spatial import ConvexHull
+        eq = ConvexHull(v).equations                      # n . x + off <= 0 inside
+    except Exception:
+        return np.zeros((0, 4))
+    scale = max(float(np.abs(v).max()), 1e-12)
+    out, seen = [], set()
+    for n0, n1, n2, off in eq:
+        key = (round(n0, 6), round(n1, 6), round(n2, 6), round(off/scale, 6))
+        if key not in seen:
+            seen.add(key)
+            out.append((n0, n1, n2, -off))
+    return np.array(out, float).reshape(-1, 4)
 
 
 class Model:
@@ -452,6 +474,16 @@ class Model:
                 verts.append(g['vertices'])
         m.mesh_vert = np.concatenate(verts) if verts else np.zeros((0, 3))
         m.nmeshvert = len(m.mesh_vert)
+        # ... and the planes of their hulls (explicit pairs with a mesh: include/fmj.h, ABI 6)
+        m.geom_faceadr = np.full(m.ngeom, -1, np.int32); m.geom_facenum = np.zeros(m.ngeom, np.int32)
+        faces = []
+        for gi, (_, g) in enumerate(geoms):
+            if g['type'] == GEOM_MESH:
+                f = hull_faces(g['vertices'])
+                m.geom_faceadr[gi] = sum(len(x) for x in faces); m.geom_facenum[gi] = len(f)
+                faces.append(f)
+        m.mesh_face = np.concatenate(faces) if faces else np.zeros((0, 4))
+        m.nmeshface = len(m.mesh_face)
         # explicit geom pairs: every geom of body1 x every geom of body2, in the order the pairs were added
         pg1, pg2, pfr, psr, psi = [], [], [], [], []
         for pr in b.pairs:
@@ -546,6 +578,7 @@ class Model:
             setattr(c, n, int(getattr(self, n)))
         c.npair = int(getattr(self, 'npair', 0))
         c.nmeshvert = int(getattr(self, 'nmeshvert', 0))
+        c.nmeshface = int(getattr(self, 'nmeshface', 0))
         c.timestep = self.timestep
         c.gravity = (ctypes.c_double*3)(*self.gravity)
         c.impratio = self.impratio
@@ -738,7 +771,6 @@ def salamander33(contacts: bool = False, limits: bool = False, full_actuators: b
             b.add_geom('world', GEOM_PLANE, (0, 0, 0), friction=(0, 0, 0))     # arena friction 0 (mjcf.py:1202)
         b.options['max_contacts'] = 40 if mesh_feet else 32     # a mesh foot makes up to 4 contacts (27 limits + 4 x 40 rows <= 192)
         if self_collisions:                 # feet against the trunk segments they can reach and against each other
-            assert not mesh_feet, 'explicit pairs need sphere / capsule geoms'
             for tag, trunk in (('front', (0, 2, 3)), ('hind', (4, 6, 7))):
                 for sname in ('L', 'R'):
                     for t in trunk:

@@ -168,7 +168,7 @@ typedef struct fmj_model {
    * mjcf.py:270-413): geom g of type FMJ_GEOM_MESH owns vertices [geom_vertadr[g], + geom_vertnum[g]) of mesh_vert, in
    * the geom frame; they stand for their convex hull.  Against the ground a mesh gives up to 4 contacts, at its deepest
    * penetrating vertices (deepest first, equal depths in vertex order).  Not MuJoCo's mjc_PlaneConvex point selection
-   * (support point + tilted directions), which is not restated here; explicit pairs with a mesh are refused. */
+   * (support point + tilted directions), which is not restated here.  Explicit pairs: see mesh_face below. */
   int32_t nmeshvert;
   const double* mesh_vert;      /* [nmeshvert,3] or NULL */
   const int32_t* geom_vertadr;  /* [ngeom] (-1: not a mesh) or NULL when nmeshvert == 0 */
@@ -201,7 +201,24 @@ typedef struct fmj_model {
   double noslip_tolerance;      /* option.noslip_tolerance (mjcf.py:1398-1403) */
   /* ABI 5 */
   int32_t integrator;           /* FMJ_INT_*: option.integrator (mjcf.py:1360-1365) */
-  int32_t reserved0;
+  /* ABI 6: explicit pairs between ANY two collision shapes (round 5; the reference emits a pair for every collision shape of every
+   * morphology.self_collisions link pair, and its usual collision shape is a convex mesh: mjcf.py:1012-1033,270-413).
+   * A box, a cylinder and a mesh are POLYTOPES: vertices (box: 8 corners; cylinder: 12 points on each rim, the first on +x, enumerated in steps of 150 degrees so that equal-depth ties keep spread-out points;
+   * mesh: mesh_vert) and outward faces (box, cylinder: analytic - the cylinder's true side surface; mesh: the planes of its hull,
+   * mesh_face[k] = unit normal n and offset d in the geom frame, n . x <= d inside).  Narrow phase of a pair (geom1, geom2), normal
+   * from geom1 to geom2, margin 0, restated by oracle collide_pair:
+   *   sphere / capsule against sphere / capsule: one contact at the closest points of the two segments (rounds 2-4);
+   *   polytope against sphere / capsule: each centre (a capsule's two end centres) against the polytope's faces: signed distance
+   *     s = max over faces (n . c - d), contact when s - radius < 0 with the face of that maximum as the normal - exact where the
+   *     closest feature is a face, an under-estimate of the distance (<= true distance) near edges and corners;
+   *   polytope against polytope: every vertex of one inside the other (s < 0) is a candidate with the other's nearest face as normal;
+   *     the (<= 4) deepest candidates are kept, deepest first, equal depths in candidate order (geom1's vertices, then geom2's):
+   *     the rule of mesh against ground.  Edge-edge crossings without a vertex inside are not found.
+   * Not MuJoCo's convex-convex pipeline (MPR / GJK + multi-contact heuristics): like the plane-mesh rule, a documented stand-in. */
+  int32_t nmeshface;
+  const double* mesh_face;      /* [nmeshface,4] or NULL */
+  const int32_t* geom_faceadr;  /* [ngeom] (-1: not a mesh) or NULL when nmeshface == 0 */
+  const int32_t* geom_facenum;  /* [ngeom] */
 } fmj_model;
 
 /* ---- per-env device buffers for the physics step -------------------------------------------

@@ -705,10 +705,141 @@ static void segment_closest(const double* c1, const double* a1, double h1, const
   *s_out = s; *t_out = t;
 }
 
-/* explicit pair 'pr' between sphere / capsule geoms g1, g2: one contact at the closest points of their segments, normal
- * from geom1 to geom2 (mjContact convention), position midway between the surfaces */
+/* ---- polytopes (box, cylinder, convex mesh) in explicit pairs: include/fmj.h, ABI 6 ------------------------------------- */
+static int geom_is_round(int t) { return t == FMJ_GEOM_SPHERE || t == FMJ_GEOM_CAPSULE; }
+static int poly_nvert(const fmj_model* m, int g) {
+  int t = m->geom_type[g];
+  return t == FMJ_GEOM_BOX ? 8 : t == FMJ_GEOM_CYLINDER ? 24 : t == FMJ_GEOM_MESH ? m->geom_vertnum[g] : 0;
+}
+/* vertex k of polytope g in the geom frame */
+static void poly_vertex(const fmj_model* m, int g, int k, double* v) {
+  const double* sz = m->geom_size + 3 * g;
+  int t = m->geom_type[g];
+  if (t == FMJ_GEOM_BOX) { v[0] = (k & 1 ? 1 : -1) * sz[0]; v[1] = (k & 2 ? 1 : -1) * sz[1]; v[2] = (k & 4 ? 1 : -1) * sz[2]; }
+  else if (t == FMJ_GEOM_CYLINDER) {            /* 12 points on each rim in steps of 150 degrees (0, 150, 300, 90, ...: equal-depth ties keep
+                                                   spread-out points), the first on +x; k < 12: the +z rim */
+    double a = (((k % 12) * 5) % 12) * (M_PI / 6.0);
+    v[0] = sz[0] * cos(a); v[1] = sz[0] * sin(a); v[2] = k < 12 ? sz[1] : -sz[1];
+  } else memcpy(v, m->mesh_vert + 3 * ((size_t)m->geom_vertadr[g] + k), 3 * sizeof(double));
+}
+/* signed distance of the point x (geom frame) to polytope g = max over its faces of (n . x - d), and that face's outward normal */
+static double poly_signed(const fmj_model* m, int g, const double* x, double* n) {
+  const double* sz = m->geom_size + 3 * g;
+  int t = m->geom_type[g];
+  double s = -1e300;
+  n[0] = n[1] = 0; n[2] = 1;
+  if (t == FMJ_GEOM_BOX) {
+    for (int k = 0; k < 3; k++) {
+      double sk = fabs(x[k]) - sz[k];
+      if (sk > s) { s = sk; n[0] = n[1] = n[2] = 0; n[k] = x[k] < 0 ? -1 : 1; }
+    }
+  } else if (t == FMJ_GEOM_CYLINDER) {
+    double r = sqrt(x[0] * x[0] + x[1] * x[1]);
+    s = fabs(x[2]) - sz[1]; n[0] = n[1] = 0; n[2] = x[2] < 0 ? -1 : 1;
+    if (r - sz[0] > s) { s = r - sz[0]; if (r > MINVAL) { n[0] = x[0] / r; n[1] = x[1] / r; } else { n[0] = 1; n[1] = 0; } n[2] = 0; }
+  } else {
+    const double* F = m->mesh_face + 4 * (size_t)m->geom_faceadr[g];
+    for (int f = 0; f < m->geom_facenum[g]; f++) {
+      double sf = F[4 * f] * x[0] + F[4 * f + 1] * x[1] + F[4 * f + 2] * x[2] - F[4 * f + 3];
+      if (sf > s) { s = sf; n[0] = F[4 * f]; n[1] = F[4 * f + 1]; n[2] = F[4 * f + 2]; }
+    }
+  }
+  return s;
+}
+static double geom_rbound(const fmj_model* m, int g) {
+  const double* sz = m->geom_size + 3 * g;
+  switch (m->geom_type[g]) {
+    case FMJ_GEOM_SPHERE: return sz[0];
+    case FMJ_GEOM_CAPSULE: return sz[0] + sz[1];
+    case FMJ_GEOM_CYLINDER: return sqrt(sz[0] * sz[0] + sz[1] * sz[1]);
+    case FMJ_GEOM_BOX: return sqrt(sz[0] * sz[0] + sz[1] * sz[1] + sz[2] * sz[2]);
+    default: return sz[2];          /* mesh: its bounding radius about the geom origin */
+  }
+}
+static void geom_pose(const fmj_model* m, const ws_t* w, int g, double* pos, double* mat) {
+  int gb = m->geom_bodyid[g];
+  double gq[4], v[3];
+  mul_quat(gq, w->xquat + 4 * gb, m->geom_quat + 4 * g);
+  rot_vec_quat(v, m->geom_pos + 3 * g, w->xquat + 4 * gb);
+  for (int i = 0; i < 3; i++) pos[i] = w->xpos[3 * gb + i] + v[i];
+  quat2mat(mat, gq);
+}
+static void to_local(const double* pos, const double* mat, const double* xw, double* xl) {
+  double d[3] = {xw[0] - pos[0], xw[1] - pos[1], xw[2] - pos[2]};
+  for (int k = 0; k < 3; k++) xl[k] = mat[k] * d[0] + mat[3 + k] * d[1] + mat[6 + k] * d[2];
+}
+static void to_world_dir(const double* mat, const double* vl, double* vw) {
+  for (int k = 0; k < 3; k++) vw[k] = mat[3 * k] * vl[0] + mat[3 * k + 1] * vl[1] + mat[3 * k + 2] * vl[2];
+}
+static void pair_emit(const fmj_model* m, ws_t* w, int pr, int g1, int g2, const double* pos, const double* n, double dist, int* warn) {
+  double mu = fmax(m->pair_friction[pr], 1e-5);        /* mjMINMU */
+  if (w->ncon >= m->max_contacts) { *warn |= FMJ_WARN_CONTACTFULL; return; }
+  add_contact(m, w, g1, g2, pos, n, dist, mu, warn);
+  w->con_pair[w->ncon - 1] = pr;
+}
+
+/* explicit pair 'pr' (geom1, geom2), normal from geom1 to geom2 (mjContact convention), margin 0.  Sphere / capsule pairs: one
+ * contact at the closest points of their segments, position midway between the surfaces.  Pairs with a box, a cylinder or a convex
+ * mesh: include/fmj.h (ABI 6). */
 static void collide_pair(const fmj_model* m, ws_t* w, int pr, int* warn) {
   int g[2] = {m->pair_geom1[pr], m->pair_geom2[pr]};
+  const int round0 = geom_is_round(m->geom_type[g[0]]), round1 = geom_is_round(m->geom_type[g[1]]);
+  if (!(round0 && round1)) {
+    double pos[2][3], mat[2][9];
+    geom_pose(m, w, g[0], pos[0], mat[0]); geom_pose(m, w, g[1], pos[1], mat[1]);
+    double dc[3] = {pos[1][0] - pos[0][0], pos[1][1] - pos[0][1], pos[1][2] - pos[0][2]};
+    if (sqrt(dotn(dc, dc, 3)) > geom_rbound(m, g[0]) + geom_rbound(m, g[1])) return;
+    if (round0 != round1) {                       /* polytope against sphere / capsule: the round geom's centres against the faces */
+      const int rk = round0 ? 0 : 1, pk = 1 - rk;
+      const double rad = m->geom_size[3 * g[rk]];
+      const int ncen = m->geom_type[g[rk]] == FMJ_GEOM_CAPSULE ? 2 : 1;
+      for (int c = 0; c < ncen; c++) {
+        const double sgn = ncen == 2 ? (c == 0 ? 1.0 : -1.0) : 0.0, half = m->geom_size[3 * g[rk] + 1];
+        double cw[3], cl[3], nl[3], nw[3];
+        for (int k = 0; k < 3; k++) cw[k] = pos[rk][k] + sgn * half * mat[rk][3 * k + 2];
+        to_local(pos[pk], mat[pk], cw, cl);
+        const double dist = poly_signed(m, g[pk], cl, nl) - rad;
+        if (!(dist < 0)) continue;
+        to_world_dir(mat[pk], nl, nw);            /* out of the polytope, towards the round geom */
+        double cp[3], n12[3];
+        for (int k = 0; k < 3; k++) { cp[k] = cw[k] - nw[k] * (rad + 0.5 * dist); n12[k] = pk == 0 ? nw[k] : -nw[k]; }
+        pair_emit(m, w, pr, g[0], g[1], cp, n12, dist, warn);
+      }
+      return;
+    }
+    /* polytope against polytope: vertices of one inside the other; the four deepest, deepest first */
+    int cnt = 0; double dq[4], cq[4][3], nq[4][3];
+    for (int side = 0; side < 2; side++) {        /* side 0: geom1's vertices in geom2; side 1: geom2's vertices in geom1 */
+      const int va = side, fb = 1 - side;
+      const int nvert = poly_nvert(m, g[va]);
+      for (int k = 0; k < nvert; k++) {
+        double vl[3], vw[3], xl[3], nl[3], nw[3];
+        poly_vertex(m, g[va], k, vl);
+        to_world_dir(mat[va], vl, vw);
+        for (int i = 0; i < 3; i++) vw[i] += pos[va][i];
+        to_local(pos[fb], mat[fb], vw, xl);
+        double td = poly_signed(m, g[fb], xl, nl);
+        if (!(td < 0)) continue;
+        to_world_dir(mat[fb], nl, nw);            /* out of the polytope the vertex is inside of */
+        double c[3], nn[3];
+        for (int i = 0; i < 3; i++) { c[i] = vw[i] - nw[i] * 0.5 * td; nn[i] = fb == 0 ? nw[i] : -nw[i]; }
+        int have = 1;
+        for (int q = 0; q < 4 && have; q++) {
+          int empty = q >= cnt;
+          if (empty || td < dq[q]) {
+            double sd = dq[q], sc[3], sn[3];
+            memcpy(sc, cq[q], sizeof sc); memcpy(sn, nq[q], sizeof sn);
+            dq[q] = td; memcpy(cq[q], c, sizeof sc); memcpy(nq[q], nn, sizeof sn);
+            td = sd; memcpy(c, sc, sizeof sc); memcpy(nn, sn, sizeof sn);
+            if (empty) have = 0;
+          }
+        }
+        if (cnt < 4) cnt++;
+      }
+    }
+    for (int q = 0; q < cnt; q++) pair_emit(m, w, pr, g[0], g[1], cq[q], nq[q], dq[q], warn);
+    return;
+  }
   double cen[2][3], ax[2][3], half[2], rad[2];
   for (int k = 0; k < 2; k++) {
     int gb = m->geom_bodyid[g[k]];
@@ -731,10 +862,7 @@ static void collide_pair(const fmj_model* m, ws_t* w, int pr, int* warn) {
   if (len < MINVAL) { n[0] = 0; n[1] = 0; n[2] = 1; } else for (int i = 0; i < 3; i++) n[i] /= len;
   double pos[3];
   for (int i = 0; i < 3; i++) pos[i] = p1[i] + n[i] * (rad[0] + 0.5 * dist);
-  double mu = fmax(m->pair_friction[pr], 1e-5);        /* mjMINMU */
-  if (w->ncon >= m->max_contacts) { *warn |= FMJ_WARN_CONTACTFULL; return; }
-  add_contact(m, w, g[0], g[1], pos, n, dist, mu, warn);
-  w->con_pair[w->ncon - 1] = pr;
+  pair_emit(m, w, pr, g[0], g[1], pos, n, dist, warn);
 }
 
 static void make_constraints(const fmj_model* m, ws_t* w, const double* qpos, const double* qvel, int* warn) {

@@ -152,8 +152,8 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     assert rc == 2 and 'FMJ_SOLVER_PGS, FMJ_SOLVER_CG or FMJ_SOLVER_NEWTON' in msg, (rc, msg)
     m = salamander33(contacts=True, limits=True, self_collisions=True)
     m.solver = SOLVERS['newton']; m.cone = 1
-    rc, msg = create(m)
-    assert rc == 2 and 'no explicit pairs' in msg, (rc, msg)
+    rc, msg = create(m)                                      # round 5: accepted (solved on the dual problem: elliptic block update + pairs)
+    assert rc in (0, 4), (rc, msg)
     m = salamander33(contacts=True, limits=True)
     m.solver = SOLVERS['newton']; m.geom_friction = m.geom_friction*0.0
     rc, msg = create(m)                                      # frictionless contacts under Newton: accepted (solved on the dual problem)

@@ -346,3 +346,106 @@ def test_mesh_keeps_its_four_deepest_vertices(oracle):
     assert np.allclose(fd['contact'][:4, 2], 0.5*depth[want], atol=1e-12)                    # midway between vertex and plane
     far = _mesh_body(v, z=0.0501)
     assert oracle.forward_debug(far, far.qpos0, np.zeros(6))['ncon'] == 0
+
+
+# ---- explicit pairs with a box, a cylinder or a convex mesh (include/fmj.h, ABI 6; reference mjcf.py:1012-1033,270-413) --------------
+
+def _stack(lower, upper, z, tilt=0.0, max_contacts=8, gravity=(0, 0, 0), **pair_kw):
+    """A welded base carrying geom `lower`, and a body on a vertical slide joint carrying geom `upper`, in an explicit pair.
+    lower / upper = (type, size[, vertices]); the slider's qpos is its height z."""
+    from farms_mujoco_amd.model import GEOM_MESH, axisangle2quat
+    b = ModelBuilder('stack', timestep=1e-3, gravity=gravity)
+    b.add_body('base', 'world', pos=(0, 0, 0), mass=1.0, inertia=(1e-3, 1e-3, 1e-3))
+    b.add_body('top', 'base', mass=0.5, inertia=(1e-3, 1e-3, 1e-3), joint='slide', axis=(0, 0, 1), damping=0.0, qpos0=0.0)
+    for body, (gt, size, *rest) in (('base', lower), ('top', upper)):
+        quat = axisangle2quat([1, 0, 0], tilt) if body == 'top' else (1, 0, 0, 0)
+        if gt == GEOM_MESH:
+            b.add_mesh_geom(body, rest[0], quat=quat)
+        else:
+            b.add_geom(body, gt, size, quat=quat)
+    b.add_contact_pair('base', 'top', **pair_kw)
+    b.options['max_contacts'] = max_contacts
+    m = b.compile()
+    return m, np.array([z])
+
+
+def _pair_contacts(oracle, m, q):
+    o = oracle.forward_debug(m, q, np.zeros(m.nv))
+    return o['contact'][:o['ncon']], o
+
+
+def test_box_on_box_pair_four_corner_contacts(oracle):
+    """Box (half 0.05) pressed 2 mm into the top face of a box (half 0.1): the upper box's four bottom corners are inside the lower
+    one; normal +z (from geom1 = lower to geom2 = upper), dist = -2 mm, position midway between corner and face, corner order."""
+    from farms_mujoco_amd.model import GEOM_BOX
+    m, q = _stack((GEOM_BOX, (0.1, 0.1, 0.1)), (GEOM_BOX, (0.05, 0.05, 0.05)), 0.1 + 0.05 - 0.002)
+    con, o = _pair_contacts(oracle, m, q)
+    assert len(con) == 4
+    assert np.allclose(con[:, 3:6], [0, 0, 1]) and np.allclose(con[:, 17], -0.002)
+    assert np.allclose(con[:, :3], [[-.05, -.05, 0.099], [.05, -.05, 0.099], [-.05, .05, 0.099], [.05, .05, 0.099]])
+    assert np.all(con[:, 15] == 0) and np.all(con[:, 16] == 1)            # geom1, geom2
+    m2, q2 = _stack((GEOM_BOX, (0.1, 0.1, 0.1)), (GEOM_BOX, (0.05, 0.05, 0.05)), 0.1 + 0.05 + 0.001)
+    assert len(_pair_contacts(oracle, m2, q2)[0]) == 0                    # 1 mm apart: nothing (margin 0)
+
+
+def test_mesh_cube_pair_equals_the_analytic_box(oracle):
+    """A cube given as a convex MESH (its 8 corners; faces from the hull) meets a box exactly as the analytic box does - in either
+    role - and the same with both shapes as meshes: the hull planes of the model compiler are the box's faces."""
+    from farms_mujoco_amd.model import GEOM_BOX, GEOM_MESH, hull_faces
+    cube = lambda h: np.array([[(i & 1)*2 - 1, ((i >> 1) & 1)*2 - 1, ((i >> 2) & 1)*2 - 1] for i in range(8)], float)*h
+    f = hull_faces(cube(0.1))
+    assert f.shape == (6, 4) and np.allclose(np.sort(f[:, 3]), 0.1) and np.allclose(np.abs(f[:, :3]).sum(1), 1.0)
+    z = 0.1 + 0.05 - 0.002
+    ref, _ = _pair_contacts(oracle, *_stack((GEOM_BOX, (0.1, 0.1, 0.1)), (GEOM_BOX, (0.05, 0.05, 0.05)), z, tilt=0.03))
+    assert 1 <= len(ref) <= 4
+    for lower, upper in (((GEOM_MESH, None, cube(0.1)), (GEOM_BOX, (0.05, 0.05, 0.05))), ((GEOM_BOX, (0.1, 0.1, 0.1)), (GEOM_MESH, None, cube(0.05))),
+                         ((GEOM_MESH, None, cube(0.1)), (GEOM_MESH, None, cube(0.05)))):
+        con, _ = _pair_contacts(oracle, *_stack(lower, upper, z, tilt=0.03))
+        assert len(con) == len(ref)
+        assert np.allclose(con[:, :12], ref[:, :12], atol=1e-12) and np.allclose(con[:, 17], ref[:, 17], atol=1e-12)
+
+
+def test_sphere_capsule_cylinder_on_a_box_pair(oracle):
+    from farms_mujoco_amd.model import GEOM_BOX, GEOM_SPHERE, GEOM_CAPSULE, GEOM_CYLINDER
+    box = (GEOM_BOX, (0.1, 0.1, 0.1))
+    # sphere r = 0.03, centre 0.128 above the centre: dist = 0.128 - 0.1 - 0.03 = -2 mm, normal +z, position 1 mm below the face
+    con, _ = _pair_contacts(oracle, *_stack(box, (GEOM_SPHERE, (0.03, 0, 0)), 0.128))
+    assert len(con) == 1 and np.allclose(con[0, 3:6], [0, 0, 1]) and np.isclose(con[0, 17], -0.002) and np.allclose(con[0, :3], [0, 0, 0.099])
+    # the same pair declared the other way round: normal from geom1 (the sphere) to geom2 (the box) = -z
+    from farms_mujoco_amd.model import ModelBuilder as MB
+    b = MB('flip', timestep=1e-3, gravity=(0, 0, 0))
+    b.add_body('base', 'world', mass=1.0, inertia=(1e-3, 1e-3, 1e-3)); b.add_geom('base', GEOM_BOX, (0.1, 0.1, 0.1))
+    b.add_body('top', 'base', mass=0.5, inertia=(1e-3, 1e-3, 1e-3), joint='slide', axis=(0, 0, 1)); b.add_geom('top', GEOM_SPHERE, (0.03, 0, 0))
+    b.add_contact_pair('top', 'base'); b.options['max_contacts'] = 4
+    mf = b.compile()
+    con, _ = _pair_contacts(oracle, mf, np.array([0.128]))
+    assert len(con) == 1 and np.allclose(con[0, 3:6], [0, 0, -1]) and np.isclose(con[0, 17], -0.002) and np.allclose(con[0, :3], [0, 0, 0.099])
+    # capsule lying along y on the face (tilted 90 degrees about x): both end centres touch
+    con, _ = _pair_contacts(oracle, *_stack(box, (GEOM_CAPSULE, (0.02, 0.06, 0)), 0.1 + 0.02 - 0.001, tilt=np.pi/2))
+    assert len(con) == 2 and np.allclose(con[:, 17], -0.001) and np.allclose(np.sort(con[:, 1]), [-0.06, 0.06]) and np.allclose(con[:, 3:6], [0, 0, 1])
+    # cylinder standing on the face: the four deepest rim points are the first four of the 150-degree enumeration: 0, 150, 300, 90 degrees
+    con, _ = _pair_contacts(oracle, *_stack(box, (GEOM_CYLINDER, (0.04, 0.05, 0)), 0.1 + 0.05 - 0.001))
+    assert len(con) == 4 and np.allclose(con[:, 17], -0.001)
+    ang = np.degrees(np.arctan2(con[:, 1], con[:, 0])) % 360
+    assert np.allclose(ang, [0, 150, 300, 90]) and np.allclose(np.hypot(con[:, 0], con[:, 1]), 0.04)
+    # a sphere beside the box, level with its top edge: the nearest face wins (x), s = max over faces
+    m, q = _stack(box, (GEOM_SPHERE, (0.03, 0, 0)), 0.05)
+    m.geom_pos = m.geom_pos.copy(); m.geom_pos[1] = [0.125, 0, 0]
+    con, _ = _pair_contacts(oracle, m, q)
+    assert len(con) == 1 and np.allclose(con[0, 3:6], [1, 0, 0]) and np.isclose(con[0, 17], 0.125 - 0.1 - 0.03)
+
+
+def test_box_rests_on_a_box_pair_and_carries_its_weight(oracle):
+    """Dynamics through the pair rows: the upper box (0.5 kg on a slide joint) settles on the lower one; the four contacts carry
+    m g together (soft contact: a small, steady penetration)."""
+    from farms_mujoco_amd.model import GEOM_BOX
+    m, q = _stack((GEOM_BOX, (0.1, 0.1, 0.1)), (GEOM_BOX, (0.05, 0.05, 0.05)), 0.1 + 0.05 + 0.001, gravity=(0, 0, -9.81), friction=0.5)
+    m.solver_iterations = 200; m.solver_tolerance = 1e-12
+    qq, vv, ww = q[None].copy(), np.zeros((1, 1)), np.zeros((1, 1))
+    for _ in range(600):
+        o = oracle.step_tf(m, qq, vv, warmstart=ww, want_AR=False)
+        qq, vv, ww = o['qpos'], o['qvel'], o['warmstart']
+    nc = int(o['ncon'][0])
+    assert nc == 4 and abs(vv[0, 0]) < 1e-4
+    assert abs(o['contact'][0, :nc, 12].sum() - 0.5*9.81) < 1e-3*0.5*9.81
+    assert -2e-3 < qq[0, 0] - 0.15 < 0

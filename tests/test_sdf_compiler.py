@@ -367,3 +367,45 @@ def test_noslip_options_reach_the_model_and_the_mjcf(sdf_path):
     assert int(opt.get('noslip_iterations')) == 7 and float(opt.get('noslip_tolerance')) == 1e-5
     m0 = sdf2model(ModelSDF.read(sdf_path)[0], animat_options=ao, simulation_options=SimulationOptions(), use_collisions=True, plane=True)
     assert m0.noslip_iterations == 0
+
+
+def test_self_collisions_between_mesh_and_box_links(tmp_path):
+    """Round 5: the reference emits a pair for every collision shape of every morphology.self_collisions link
+    pair (mjcf.py:1012-1033) and its usual collision shape is a convex mesh (mjcf.py:270-413).  An SDF animat with a mesh link, a box
+    link and self_collisions compiles: the pair joins the mesh geom and the box geom, the mesh carries the planes of its hull, the
+    C model hands them on, and the oracle finds the contact when the two links overlap."""
+    from farms_mujoco_amd.io.sdf import ModelSDF
+    from farms_mujoco_amd.options import AnimatOptions, ArenaOptions, SimulationOptions
+    from farms_mujoco_amd.simulation.mjcf import setup_model
+    tet = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1]], float)
+    (tmp_path / 'tet.obj').write_text(''.join(f'v {a} {b} {c}\n' for a, b, c in tet))
+    (tmp_path / 'm.sdf').write_text('''<sdf version="1.6"><model name="m">
+      <link name="base"><pose>0 0 0.2 0 0 0</pose>
+        <inertial><mass>0.3</mass><inertia><ixx>1e-4</ixx><iyy>1e-4</iyy><izz>1e-4</izz></inertia></inertial>
+        <collision name="c"><geometry><mesh><uri>tet.obj</uri><scale>0.1 0.1 0.1</scale></mesh></geometry></collision>
+      </link>
+      <link name="arm"><pose>0.02 0.02 0.2 0 0 0</pose>
+        <inertial><mass>0.1</mass><inertia><ixx>1e-5</ixx><iyy>1e-5</iyy><izz>1e-5</izz></inertia></inertial>
+        <collision name="c"><geometry><box><size>0.02 0.02 0.02</size></box></geometry></collision>
+      </link>
+      <joint name="j" type="revolute"><parent>base</parent><child>arm</child><axis><xyz>0 0 1</xyz><limit><lower>-1</lower><upper>1</upper></limit></axis></joint>
+    </model></sdf>''')
+    ao = AnimatOptions(name='m', links=[AnimatOptions.link(n) for n in ('base', 'arm')], joints=[AnimatOptions.joint('j', damping=1e-3)],
+                       motors=[], sdf=str(tmp_path / 'm.sdf'))
+    ao.morphology.self_collisions = [['base', 'arm']]
+    m = setup_model(SimulationOptions(timestep=1e-3), ao, ArenaOptions())
+    assert m.npair == 1
+    g1, g2 = int(m.pair_geom1[0]), int(m.pair_geom2[0])
+    assert {int(m.geom_type[g1]), int(m.geom_type[g2])} == {7, 6}                    # a mesh and a box
+    gm = g1 if m.geom_type[g1] == 7 else g2
+    assert m.nmeshface == 4 and m.geom_facenum[gm] == 4 and m.geom_faceadr[gm] == 0
+    f = np.asarray(m.mesh_face)
+    assert np.allclose(np.linalg.norm(f[:, :3], axis=1), 1.0)
+    v = np.asarray(m.mesh_vert)
+    assert (f[:, :3] @ v.T - f[:, 3:4] < 1e-12).all()                                  # every vertex inside every plane
+    c = m.as_c()
+    assert c.nmeshface == 4 and c.mesh_face[3] == f[0, 3]
+    from oracle import oracle as orc
+    orc.build()
+    o = orc.forward_debug(m, m.qpos0, np.zeros(m.nv))
+    assert o['ncon'] >= 1 and (o['contact'][:o['ncon'], 17] < 0).all()               # the box's corner sits inside the tetrahedron
