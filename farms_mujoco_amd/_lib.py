@@ -59,7 +59,7 @@ class CFusedArgs(ctypes.Structure):
                 ('row_stride_contacts', ctypes.c_int64),
                 ('rows_base', CRows), ('water', CWater), ('units', CUnits), ('wave', CWave), ('ctrl_out', _VP),
                 ('env_order', _VP), ('substeps', ctypes.c_int32), ('substep_links', ctypes.c_int32),
-                ('n_iterations', ctypes.c_int32), ('reserved0', ctypes.c_int32)]
+                ('n_iterations', ctypes.c_int32), ('rows_ahead', ctypes.c_int32)]
 
 
 BEFORE_ROWS, BEFORE_LINKS_ONLY, BEFORE_CONTACTS, BEFORE_DRAG = 1, 2, 4, 8      # FMJ_BEFORE_* of include/fmj.h

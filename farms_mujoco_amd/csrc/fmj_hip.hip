@@ -165,6 +165,7 @@ struct StepArgs {
   float* xpos; float* xquat; float* xipos; float* sensordata; float* qacc; float* time; int* status;
   float* qacc_warmstart; float* contact; int* ncon; float* contacts_rows; float inv_newtons;
   int n_envs, n_steps, iteration0, buffer_size, do_readout, do_drag, controller, integrate, disable_actuation;
+  int rows_ahead;             // fused: fmj_fused_args::rows_ahead (the two-env unconstrained kernel only)
   int n_it_total;             // fused: fmj_fused_args::n_iterations (0 = unknown): a sub-step whose task.iteration reached it writes no rows
   int substeps, sub_links;    // fused: physics steps per iteration (>= 1); sub-steps write links-only rows + drag (include/fmj.h)
   long long ctrl_step_stride, row_stride_links, row_stride_joints, row_stride_xfrc, row_stride_contacts;
@@ -2974,6 +2975,10 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   fill_units(&A, &a->units); fill_water(&A, &a->water);
   A.w_amp = a->wave.amplitude; A.w_lag = a->wave.phase_lag; A.w_env = a->wave.env_phase; A.w_freq = a->wave.frequency;
   A.ctrl_out = a->controller == 1 ? a->ctrl_out : nullptr;
+  if (a->rows_ahead) {
+    if (!c->dm.dual_ok || A.substeps != 1) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_step_fused: rows_ahead needs the two-env unconstrained step kernel and substeps = 1 (write the rows with fmj_before_step instead)");
+    A.rows_ahead = 1; A.xfrc_applied_out = (float*)d->xfrc_applied;
+  }
   A.env_order = c->dm.dual_ok ? nullptr : a->env_order;      // the two-env constraint kernel pairs neighbours of the order: similar row counts
   HIP_TRY(hipSetDevice(c->device));
   return launch_step(c, true, A, stream);

@@ -88,23 +88,34 @@ class Simulation:
     def reset(self):
         self.task.initialize_episode(self.physics)
         self._needs_reset = False
+        self._rows_for, self._ahead_ok = -1, None
 
     # ---- stepping ---------------------------------------------------------------------------------------
     def _env_step(self):
-        """Environment.step(action=None): before_step -> physics.step -> after_step.  Two launches when the task's
-        callbacks run on the host: the sensors' (+ the swimming callback's drag, fmj_before_step) and the step's - which also
-        evaluates a device controller (task.controller_in_step) -; round 4 took four and a handful of torch kernels for the ctrl write."""
-        task = self.task
-        task.before_step(None, self.physics)
+        """Environment.step(action=None): before_step -> physics.step -> after_step.  With host callbacks an iteration is
+        ONE launch where the model allows it (swimming, no constraints: the step's launch also writes the next iteration's rows, drag
+        and xfrc_applied - fmj_fused_args::rows_ahead - so before_step finds them done) and two otherwise (fmj_before_step, then the
+        step, which also evaluates a device controller); round 4 took four and a handful of torch kernels for the ctrl write."""
+        task, phys = self.task, self.physics
+        if getattr(self, '_ahead_ok', None) is None:
+            self._ahead_ok = task.rows_ahead_ok(phys)
+        have_rows = getattr(self, '_rows_for', -1) == task.sim_iteration       # the previous launch wrote this iteration's rows
+        task.before_step(None, phys, rows_written=have_rows)
         if task.controller_in_step() and task.sim_iteration % task.substeps == 0:
-            self._step_with_controller()
+            # rows ahead: only when this iteration's own rows are in place (the first iteration gets them from before_step) and another
+            # iteration follows (the row after the run's last would be ring index n_iterations % buffer_size: row 0 of a full log)
+            ahead = self._ahead_ok and task.iteration + 1 < task.n_iterations
+            self._step_with_controller(rows_ahead=ahead)
+            self._rows_for = task.sim_iteration + 1 if ahead else -1
         else:
-            self.physics.step(1)
-        task.after_step(self.physics)
+            phys.step(1)
+            self._rows_for = -1
+        task.after_step(phys)
 
-    def _step_with_controller(self):
-        """One mj_step whose launch evaluates the device controller first (fmj_step_fused: one step, no rows, no drag - before_step
-        wrote them; xfrc_applied and qpos_spring are read from physics.data as fmj_step does)."""
+    def _step_with_controller(self, rows_ahead=False):
+        """One mj_step whose launch evaluates the device controller first (fmj_step_fused of one step).  Without ``rows_ahead`` no rows
+        and no drag: before_step wrote them, xfrc_applied and qpos_spring are read from physics.data as fmj_step does.  With it the
+        launch also writes what before_step would write for the NEXT iteration."""
         task, phys = self.task, self.physics
         a = getattr(self, '_step_args', None)
         if a is None:
@@ -112,6 +123,17 @@ class Simulation:
             a.n_steps, a.buffer_size, a.substeps = 1, task.buffer_size, 1
             a.units = task.units.as_c()
         a.iteration0 = task.iteration
+        a.rows_ahead = int(rows_ahead)
+        a.do_readout = a.do_drag = 0
+        if rows_ahead:
+            sens = task.data.sensors
+            a.do_readout = 1
+            a.rows_base.links, a.rows_base.joints, a.rows_base.xfrc = sens.links.array.data_ptr(), sens.joints.array.data_ptr(), sens.xfrc.array.data_ptr()
+            a.row_stride_links, a.row_stride_joints, a.row_stride_xfrc = sens.links.array.stride(0), sens.joints.array.stride(0), sens.xfrc.array.stride(0)
+            swim = [cb for cb in task._callbacks if isinstance(cb, SwimmingCallback)]
+            a.do_drag = int(bool(swim) and swim[0].handler.drag)
+            if swim:
+                a.water = swim[0].handler.water.as_c(use_buoyancy=swim[0].handler.buoyancy)
         c = task._controller
         cd = phys._cdata()
         if getattr(c, 'tape', False):
@@ -181,6 +203,7 @@ class Simulation:
         # advanced one sub-step early, except that nothing follows the launch's last full step yet)
         task.sim_iteration += n_steps*task.substeps
         task.iteration = (task.sim_iteration + 1)//task.substeps if task.substeps > 1 else task.sim_iteration
+        self._rows_for = -1
         return n_steps
 
     def run(self, fused=None, chunk=None):
@@ -259,6 +282,7 @@ class Simulation:
                                  f'{self.physics.n_envs}, {task.substeps}, {task.buffer_size}')
             self.physics.set_state({k[len('physics/'):]: z[k] for k in z.files if k.startswith('physics/')})
             task.iteration, task.sim_iteration = it, sim_it
+            self._rows_for = -1
             c = task._controller
             cs = {k[len('controller/'):]: z[k] for k in z.files if k.startswith('controller/')}
             if cs:

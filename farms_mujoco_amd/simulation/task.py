@@ -18,6 +18,7 @@ def duration2nit(duration: float, timestep: float) -> int:
 class TaskCallback:
     """Task callback (reference task.py:415-446): identical hooks; ``physics`` is the batched physics."""
 
+    writes_state = False     # set True in a callback that edits physics.data.qpos / qvel itself (ExperimentTask.rows_ahead_ok)
     writes_ctrl = False      # set True in a callback that writes physics.data.ctrl itself: the step then takes ctrl from there (ExperimentTask.controller_in_step)
 
     def __init__(self, substep=False):
@@ -165,6 +166,18 @@ class ExperimentTask:
         physics2data(physics=physics, iteration=index, data=self.data, maps=self.maps, units=self.units,
                      links_only=links_only, swimming=swimming)
 
+    def rows_ahead_ok(self, physics):
+        """True when the step's launch can also write the NEXT iteration's rows (one launch per iteration with host callbacks): a device
+        controller evaluated in the step, no sub-steps, the swimming callback (if any) first among the callbacks, no contact sensors
+        and the two-env unconstrained kernel (fmj_step_fused refuses rows_ahead otherwise).  A callback that edits qpos / qvel itself
+        sets ``writes_state = True``: the rows of its iteration are then read after it ran, as the reference reads them."""
+        if not self.controller_in_step() or physics.has_constraints or physics.kernel_info()['threads_per_env'] != 32:
+            return False
+        if any(getattr(cb, 'writes_state', False) for cb in self._callbacks) or self.data.sensors.contacts.names:
+            return False
+        swims = [i for i, cb in enumerate(self._callbacks) if isinstance(cb, SwimmingCallback)]
+        return swims in ([], [0])
+
     def controller_in_step(self):
         """True when the controller is evaluated by the step launch itself (Simulation._env_step -> fmj_step_fused of one step):
         a device controller (``fusable``) in a run without sub-steps whose host callbacks do not write ``physics.data.ctrl``
@@ -173,8 +186,9 @@ class ExperimentTask:
         return (c is not None and getattr(c, 'fusable', False) and self.substeps == 1
                 and not any(getattr(cb, 'writes_ctrl', False) for cb in self._callbacks))
 
-    def before_step(self, action, physics):
-        """Operations before physics step (reference task.py:168-186)."""
+    def before_step(self, action, physics, rows_written=False):
+        """Operations before physics step (reference task.py:168-186).  ``rows_written``: the sensors' rows and the swimming callback's
+        drag of this iteration are already there - the previous step's launch wrote them (fmj_fused_args::rows_ahead)."""
         # the reference asserts iteration < n_iterations here; with sub-steps its own counter reaches n_iterations one sub-step
         # before the run ends (task.py:352-355) and only dm_control's reset-on-first-step, which costs the run its last
         # environment step (SURVEY Appendix C.13), keeps that assert from firing.  run() here advances all n_iterations * substeps
@@ -187,7 +201,7 @@ class ExperimentTask:
         sensors = (full_step or self.substeps_links) and in_run
         # a swimming callback that comes first has its drag computed by the sensors' own launch (fmj_before_step)
         swim = callbacks[0] if sensors and callbacks and isinstance(callbacks[0], SwimmingCallback) and callbacks[0].handler is not None else None
-        if sensors:
+        if sensors and not rows_written:
             self.update_sensors(physics=physics, links_only=not full_step, swimming=None if swim is None else swim.handler)
         for callback in callbacks:
             if callback is not swim:

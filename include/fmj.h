@@ -454,7 +454,12 @@ typedef struct fmj_fused_args {
                                sub-step before the run ends (task.py:352-355); the reference never executes that sub-step's before_step
                                (its assert at task.py:170; dm_control's first step only resets), here it runs and writes NO rows and
                                keeps the drag force it has - the ring index n_iterations % buffer_size would be row 0 of a full log */
-  int32_t reserved0;
+  int32_t rows_ahead;       /* != 0 (the per-iteration host path, Simulation.run(fused=False)): everything before_step writes for the launch's FIRST
+                               iteration is already there (fmj_before_step, or the launch before) and xfrc_applied may have been edited by host
+                               callbacks since: nothing of it is written, the drag force is read from fmj_data::xfrc_applied; the launch
+                               writes instead, after its last step, the rows, the drag and xfrc_applied of the iteration that FOLLOWS it - an
+                               iteration with host callbacks is then ONE launch.  Models without constraints that run two envs per wave only
+                               (FMJ_ERR_UNSUPPORTED otherwise), substeps <= 1, xfrc_applied not NULL when do_drag. */
 } fmj_fused_args;
 
 int fmj_step_fused(fmj_ctx* ctx, const fmj_data* d, const fmj_fused_args* args, void* hip_stream);

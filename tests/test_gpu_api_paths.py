@@ -521,3 +521,58 @@ def test_postprocess_writes_the_log_and_options(tmp_path):
     assert os.path.exists(tmp_path / 'animat_options.yaml')
     xml = open(sim.save_mjcf_xml(str(tmp_path / 'model.xml'))).read()
     assert xml.count('<body ') == m.nbody - 1 and 'solver="PGS"' in xml
+
+
+def test_host_callbacks_with_one_launch_per_iteration():
+    """Round 5: with a host callback an iteration of Simulation.run is ONE launch for a swimming model - the
+    step's launch also writes the next iteration's rows, drag and xfrc_applied (fmj_fused_args::rows_ahead) - instead of the sensors'
+    launch plus the step's.  The callback must see what it saw before: the rows of ITS iteration, the drag already in xfrc_applied, and
+    what it adds to xfrc_applied must reach the step.  Compared with the two-launch path: equal to the fp32 rounding of the drag operator
+    (the standalone operator and the in-kernel drag differ in the last bit, tests/test_gpu_fused_parity.py)."""
+    import torch
+    from farms_mujoco_amd.simulation.task import TaskCallback
+
+    class Push(TaskCallback):
+        def __init__(self):
+            super().__init__()
+            self.seen = []
+
+        def before_step(self, task, action, physics):
+            idx = task.iteration % task.buffer_size
+            row = task.data.sensors.links.array[idx]
+            self.seen.append((task.iteration, row[:, 3, :3].clone(), task.data.sensors.joints.array[idx][:, 5, 0].clone(),
+                              physics.data.xfrc_applied[:, 4, :3].clone()))
+            if 5 <= task.iteration < 10:
+                physics.data.xfrc_applied[:, 7, 1] += 0.02           # a sideways push on one link, on top of its drag
+
+    def run(ahead):
+        sim, m, _ = _swim_sim(6, 40, controller='wave')
+        cb = Push()
+        sim.task._callbacks.append(cb)
+        assert not sim.task.fusable()
+        sim._ahead_ok = None if ahead else False
+        sim.run()
+        torch.cuda.synchronize()
+        assert (sim._ahead_ok is True) == ahead
+        s = sim.task.data.sensors
+        return sim, cb, {k: getattr(s, k).array.cpu().numpy() for k in ('links', 'joints', 'xfrc')}
+    sim_a, cb_a, rows_a = run(True)
+    sim_b, cb_b, rows_b = run(False)
+    close = lambda a, b, tol=5e-4: _relerr(_f64(a) if hasattr(a, 'cpu') else a, _f64(b) if hasattr(b, 'cpu') else b) < tol
+    for k in rows_a:
+        assert close(rows_a[k], rows_b[k]), (k, _relerr(rows_a[k], rows_b[k]))
+    for f in ('qpos', 'qvel', 'xfrc_applied', 'ctrl', 'sensordata'):
+        assert close(getattr(sim_a.physics.data, f), getattr(sim_b.physics.data, f)), f
+    assert torch.equal(sim_a.physics.data.time, sim_b.physics.data.time)
+    assert len(cb_a.seen) == len(cb_b.seen) == 40
+    for (ia, la, ja, xa), (ib, lb, jb, xb) in zip(cb_a.seen, cb_b.seen):
+        assert ia == ib and close(la, lb) and close(ja, jb) and close(xa, xb), ia
+    assert torch.equal(cb_a.seen[0][1], cb_b.seen[0][1])           # iteration 0: both read the reset's rows, written by the same operator
+    assert float(cb_a.seen[7][3].abs().max()) > 0                  # the callback saw the drag of its iteration in xfrc_applied
+    # ... and the push moved the animal: the same run without it ends elsewhere
+    sim_c, _, _ = _swim_sim(6, 40, controller='wave')
+    sim_c.run(fused=False)
+    assert not torch.equal(sim_c.physics.data.qpos, sim_a.physics.data.qpos)
+    # a callback that edits the state itself opts out of the look-ahead
+    cb_a.writes_state = True
+    assert not sim_a.task.rows_ahead_ok(sim_a.physics)
