@@ -59,3 +59,10 @@ def fp32_floor_of_solve(H, rhs):
 def scaled_condition(H):
     d = 1.0/np.sqrt(np.diag(H))
     return float(np.linalg.cond(H*np.outer(d, d)))
+
+
+def within_floor(err, floor_err, k=6.0, abs_tol=0.0):
+    """A bound stated against the yardstick instead of a fitted number: ``err`` (HIP against the fp64 oracle) may be
+    ``k`` times what the fp64 oracle WITH fp32 STORAGE (oracle.fp32_storage(level): the floor of any fp32 engine) differs from the plain
+    oracle by, in the same metric on the same run, plus ``abs_tol`` for quantities whose floor is exactly zero."""
+    return err <= k*floor_err + abs_tol

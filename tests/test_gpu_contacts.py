@@ -296,7 +296,16 @@ def test_fused_walk_contact_rows_vs_oracle(oracle, solver):
     print(solver, 'contact rows vs oracle: force rel err', err_f, 'position abs err', err_p, 'peak force', scale)
     assert err_f < 1e-3 and err_p < 2e-4 and scale > 0.05         # measured 5e-5 / 1.6e-5 with either solver
     assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < (2e-3 if solver == 'pgs' else 2e-4)
-    assert _relerr(data.sensors.joints.array.cpu().numpy()[..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]]) < 2e-2
+    # joint rows (position, velocity, limit force): stated against the floor - the same run of the fp64 oracle with every stored array
+    # in fp32 (level 3) - instead of the fitted 2e-2 of round 4 (the velocity column is what is loose: 40 steps of an ill-conditioned solve)
+    from parity_metrics import within_floor
+    with oracle.fp32_storage(3):
+        fl = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                              n_contact_rows=len(pairs), n_threads=8)
+    cols = [0, 1, 9]
+    e_j = _relerr(data.sensors.joints.array.cpu().numpy()[..., cols], ref['joints'][..., cols]); f_j = _relerr(fl['joints'][..., cols], ref['joints'][..., cols])
+    print(solver, 'joint rows (q, qd, limit force): HIP', e_j, 'fp32-storage floor', f_j)
+    assert within_floor(e_j, f_j, k=6, abs_tol=1e-5) and e_j < 2e-2
 
 
 def test_fused_walk_with_contact_rows(oracle):
@@ -816,7 +825,14 @@ def test_mesh_on_heightfield_and_fused_rows(oracle):
     assert int(d.status.abs().sum()) == 0
     rows = data.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
     scale = np.abs(want[..., :9]).max()
-    assert scale > 0.05 and np.abs(rows[..., :9] - want[..., :9]).max()/scale < 3e-2
+    # contact rows of mesh feet on a heightfield after T free-running steps: against the floor (fp64 oracle, fp32 storage of every array)
+    from parity_metrics import within_floor
+    with oracle.fp32_storage(3):
+        fl = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                              n_contact_rows=len(pairs), n_threads=8)
+    e_c = np.abs(rows[..., :9] - want[..., :9]).max()/scale; f_c = np.abs(fl['contacts'][..., :9] - want[..., :9]).max()/scale
+    print('mesh on heightfield: contact rows HIP', e_c, 'fp32-storage floor', f_c)
+    assert scale > 0.05 and within_floor(e_c, f_c, k=6, abs_tol=1e-4) and e_c < 3e-2
     assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3
 
 
@@ -1000,7 +1016,13 @@ def test_fused_walk_with_substeps(oracle, monkeypatch, substeps, dual):
     assert err_f < 2e-3 and scale > 0.05
     assert _relerr(d.qpos.cpu().numpy(), ref['qpos']) < 2e-3
     assert _relerr(data_f.sensors.links.array.cpu().numpy(), ref['links']) < 2e-3
-    assert _relerr(ja[..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]]) < 2e-2
+    from parity_metrics import within_floor
+    with oracle.fp32_storage(3):
+        fl = oracle.run_fused(m, st, T, swim=None, buffer_size=T, controller=0, ctrl=np.zeros((n, m.nu)), geompair2data=g2d,
+                              n_contact_rows=len(pairs), n_threads=8, substeps=S)
+    e_j = _relerr(ja[..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]]); f_j = _relerr(fl['joints'][..., [0, 1, 9]], ref['joints'][..., [0, 1, 9]])
+    print('substeps', S, 'joint rows: HIP', e_j, 'fp32-storage floor', f_j)
+    assert within_floor(e_j, f_j, k=6, abs_tol=1e-5) and e_j < 2e-2
 
 
 def test_fused_walk_one_long_launch_equals_many_short_ones(oracle):

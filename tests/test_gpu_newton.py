@@ -188,8 +188,11 @@ def test_newton_and_cg_with_self_collision_pairs(oracle, solver):
             fs = max(np.abs(o['contact'][e, :nc, 12]).max(), 1e-2)
             worst = max(worst, np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max()/fs)
     err = group_relerr(d.qvel.cpu().numpy(), o['qvel'], qvel_groups(m))
-    print(solver, 'with self-collision pairs: contact-frame forces', worst, 'qvel per component', err)
-    assert worst < 3e-3 and err < 3e-2
+    with oracle.fp32_storage(2):      # the floor of the velocity bound: the same step with fp32 state, poses and mass matrices
+        fl = oracle.step_tf(mo, q32, v32, ctrl=np.zeros((n, m.nu)), warmstart=w32, want_AR=False)
+    floor = group_relerr(fl['qvel'], o['qvel'], qvel_groups(m))
+    print(solver, 'with self-collision pairs: contact-frame forces', worst, 'qvel per component', err, 'fp32-storage floor', floor)
+    assert worst < 3e-3 and err < 6*floor + 1e-5 and err < 3e-2
     phys.step(39)
     torch.cuda.synchronize()
     ref = oracle.step(mo, q32, v32, ctrl=np.zeros((n, m.nu)), n_steps=40, n_threads=8)
@@ -359,6 +362,8 @@ def test_primal_solvers_on_random_contact_trees(oracle, seed, solver, cone):
     torch.cuda.synchronize()
     assert int((d.status & ~FMJ_WARN_CONTACTFULL).abs().sum()) == 0
     o = oracle.step_tf(mo, q32, v32, ctrl=c32, warmstart=w32, want_AR=False)
+    with oracle.fp32_storage(3):
+        fl = oracle.step_tf(mo, q32, v32, ctrl=c32, warmstart=w32, want_AR=False)
     assert np.array_equal(d.ncon.cpu().numpy(), o['ncon'])
     if o['nefc'].max() == 0:
         pytest.skip('no active constraint in this draw')
@@ -367,7 +372,11 @@ def test_primal_solvers_on_random_contact_trees(oracle, seed, solver, cone):
         nc = int(o['ncon'][e])
         if nc:
             fs = max(np.abs(o['contact'][e, :nc, 12:15]).max(), 1e-2)
-            assert np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max() < 2e-2*fs + 2e-3, (seed, e, con[e, :nc, 12:15], o['contact'][e, :nc, 12:15])
+            # contact-frame forces of random contact trees: 6 x the floor (the same step of the fp64 oracle with fp32 storage of every array)
+            # + 3e-3 of the largest force (what the fp32 primal iteration resolves: tests above), instead of round 4's fitted 2e-2 fs + 2e-3
+            ef = np.abs(con[e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max()
+            ff = np.abs(fl['contact'][e, :nc, 12:15] - o['contact'][e, :nc, 12:15]).max() if int(fl['ncon'][e]) == nc else 0.0
+            assert ef <= 6*ff + 3e-3*fs + 1e-4, (seed, e, ef, ff, fs)
     ev = np.abs(d.qvel.cpu().numpy() - o['qvel']).max()/max(np.abs(o['qvel']).max(), 1e-9)
     assert ev < 3e-3, (seed, m.nbody, m.nv, ev)
 
