@@ -59,6 +59,10 @@ def build_sim(n_envs, n_iterations, chunk, env_offset, device, workload='swim', 
     if workload.startswith('walk'):       # walk_pairs / walk_hfield / walk_mesh: the same walker with self-collision pairs, on a heightfield, on mesh feet
         m = mm.salamander33(contacts=True, limits=True, spawn_z=0.045, self_collisions=workload in ('walk_pairs', 'walk_pairs_newton'),
                             terrain='hfield' if workload == 'walk_hfield' else 'plane', mesh_feet=workload == 'walk_mesh')
+        if workload == 'walk_elliptic_pgs':          # round 5: MuJoCo's PGS with elliptic cones (block update + friction QCQP per contact)
+            m.cone = mm.CONES['elliptic']
+        if workload == 'walk_noslip':                # round 5: PGS x 50 followed by the noslip post-pass
+            m.noslip_iterations = 10
         if workload in ('walk_newton', 'walk_cg', 'walk_elliptic', 'walk_pairs_newton'):     # MuJoCo's Newton / CG solver with its default settings instead of PGS x 50
             m.solver = mm.SOLVERS['cg' if workload == 'walk_cg' else 'newton']; m.solver_iterations = 100
             if workload == 'walk_elliptic':
@@ -266,7 +270,7 @@ def main():
                          'external sampler with a 5 s period sees the GPU busy (VERDICT round 4: with 2 s the driver\'s gpu_busy read 2 %%)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-extras', action='store_true', help='skip the short walk / mixed measurements appended to the swim line')
-    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh', 'walk_newton', 'walk_cg', 'walk_elliptic', 'walk_pairs_newton'],
+    ap.add_argument('--workload', default='swim', choices=['swim', 'walk', 'mixed', 'walk_pairs', 'walk_hfield', 'walk_mesh', 'walk_newton', 'walk_cg', 'walk_elliptic', 'walk_pairs_newton', 'walk_elliptic_pgs', 'walk_noslip'],
                     help='swim = headline (BASELINE configs[1]); walk = configs[3]; mixed = configs[4] eel + centipede; walk_pairs / '
                          'walk_hfield / walk_mesh = the walker with self-collision pairs / on a heightfield / on convex-mesh feet')
     ap.add_argument('--dist-backend', default='gloo',
@@ -431,7 +435,8 @@ def main():
         names = {'swim': 'salamander swim (~40 DoF)', 'walk': 'salamander walk on plane (PGS contacts)', 'mixed': 'eel + centipede swim (bucketed)',
                  'walk_pairs': 'salamander walk on plane with self-collision pairs', 'walk_hfield': 'salamander walk on a heightfield',
                  'walk_mesh': 'salamander walk on convex-mesh feet', 'walk_newton': 'salamander walk on plane (Newton solver)', 'walk_cg': 'salamander walk on plane (CG solver)', 'walk_elliptic': 'salamander walk on plane (Newton solver, elliptic cone)',
-                 'walk_pairs_newton': 'salamander walk on plane with self-collision pairs (Newton solver)'}
+                 'walk_pairs_newton': 'salamander walk on plane with self-collision pairs (Newton solver)',
+                 'walk_elliptic_pgs': 'salamander walk on plane (PGS, elliptic cone)', 'walk_noslip': 'salamander walk on plane (PGS + noslip)'}
         out = {
             'metric': f'env-steps/sec, {names[args.workload]} \u00d7{n_envs} envs, 1/2/4/8 MI355X',
             'value': n_envs*world*K*R/dt, 'unit': 'env-steps/s', 'n_gpus': world, 'steps': K, 'warmup': W,
@@ -453,6 +458,8 @@ def main():
                                     'walk_cg': f'{n_envs}x salamander-33 walking on a plane, CG solver (tolerance 1e-8, <= 100 iterations) instead of PGS',
                                     'walk_elliptic': f'{n_envs}x salamander-33 walking on a plane, Newton solver with the elliptic friction cone',
                                     'walk_pairs_newton': f'{n_envs}x salamander-33 walking on a plane, 16 explicit self-collision pairs, Newton solver',
+                                    'walk_elliptic_pgs': f'{n_envs}x salamander-33 walking on a plane, PGS <= 50 sweeps with elliptic cones (block update + QCQP per contact)',
+                                    'walk_noslip': f'{n_envs}x salamander-33 walking on a plane, PGS <= 50 sweeps + 10 noslip iterations',
                                     'mixed': f'BASELINE configs[4]: {n_envs//2}x eel (nv 26) + {n_envs - n_envs//2}x centipede (nv 61) swimming per '
                                              f'GPU, one bucket (launch, HIP stream) per morphology, launched side by side'}[args.workload],
                        'envs_per_gpu': n_envs, 'steps_per_launch': chunk, 'sharding': 'independent envs, no collective',

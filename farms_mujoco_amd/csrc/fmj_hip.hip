@@ -2511,6 +2511,10 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     D.maxefc = cons ? nlimj + 4 * D.max_contacts : 0;
     // the HBM constraint path keeps A in rows of AG_LD floats and three 64-row slots per lane (fmj_cons_rows.inc)
     if (D.maxefc > AG_LD) { fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: more than 192 constraint rows possible (limited joints + 4 * max_contacts): lower max_contacts"); }
+    // the block solvers (elliptic PGS, noslip) keep forces, b, R and mu of every row in the LDS staging area of the row code: min(maxefc, 64) * rs floats
+    if (cons && (m->noslip_iterations > 0 || (m->cone == FMJ_CONE_ELLIPTIC && (m->solver == FMJ_SOLVER_PGS || dual_instead))) && std::min(D.maxefc, FMJ_NA) * D.rs < 4 * D.maxefc) {
+      fmj_destroy(c); return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: PGS with the elliptic cone / noslip: too many constraint rows for this model's row length (needs min(maxefc, 64) * rs >= 4 * maxefc): lower max_contacts");
+    }
   }
   D.implicitfast = m->integrator == FMJ_INT_IMPLICITFAST;
   D.solver_iterations = dual_instead ? 10 * m->solver_iterations : m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;

@@ -576,3 +576,64 @@ def test_host_callbacks_with_one_launch_per_iteration():
     # a callback that edits the state itself opts out of the look-ahead
     cb_a.writes_state = True
     assert not sim_a.task.rows_ahead_ok(sim_a.physics)
+
+
+def test_before_step_operator_equals_the_three_operators(oracle):
+    """fmj_before_step (ABI 6) = fmj_physics2data + fmj_contacts2data + fmj_drag in one launch, bit for bit: swimming (rows + drag +
+    xfrc_applied) and walking (rows + contact rows), full rows and links-only rows."""
+    import torch
+    from farms_mujoco_amd import _lib
+    from farms_mujoco_amd.simulation.physics import physics2data
+    from farms_mujoco_amd.sensors.sensors import cycontacts2data
+    # swimming
+    sim, m, _ = _swim_sim(5, 4)
+    sim.step_fused(3)                                    # a state with velocities
+    phys, task = sim.physics, sim.task
+    h = task._callbacks[0].handler
+    s = task.data.sensors
+
+    def three(index, links_only):
+        rows = _lib.CRows(); rows.links = s.links.array[index].data_ptr(); rows.joints = s.joints.array[index].data_ptr()
+        c = phys._cdata(); u = task.units.as_c()
+        _lib.check(phys._lib.fmj_physics2data(phys._ctx, ctypes.byref(c), ctypes.byref(rows), ctypes.byref(u), int(links_only),
+                                              ctypes.c_void_p(torch.cuda.current_stream(phys.device).cuda_stream)))
+        h.step(index)
+    for links_only in (False, True):
+        for arr in (s.links.array, s.joints.array, s.xfrc.array):
+            arr.zero_()
+        phys.data.xfrc_applied.zero_()
+        three(1, links_only)
+        want = [a[1].clone() for a in (s.links.array, s.joints.array, s.xfrc.array)] + [phys.data.xfrc_applied.clone()]
+        for arr in (s.links.array, s.joints.array, s.xfrc.array):
+            arr.zero_()
+        phys.data.xfrc_applied.zero_()
+        physics2data(phys, 1, task.data, task.maps, task.units, links_only=links_only, swimming=h)
+        got = [a[1] for a in (s.links.array, s.joints.array, s.xfrc.array)] + [phys.data.xfrc_applied]
+        for w, g, name in zip(want, got, ('links', 'joints', 'xfrc', 'xfrc_applied')):
+            assert torch.equal(w, g), (name, links_only)
+        assert float(want[0].abs().max()) > 0 and float(want[3].abs().max()) > 0 and (links_only or float(want[1].abs().max()) > 0)
+    # walking: contact rows
+    from farms_mujoco_amd.data import AnimatData
+    from farms_mujoco_amd.model import salamander33
+    from farms_mujoco_amd.options import SimulationOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    mw = salamander33(contacts=True, limits=True, spawn_z=0.03)
+    pairs = [(b, '') for b in mw.body_names[1:] if b.endswith('_3')] + [('world', '')]
+    data = AnimatData(mw.timestep, 4, 3, mw.body_names[1:], mw.hinge_joint_names(), contacts=pairs)
+    simw = Simulation(mw, mw.body_names[1], SimulationOptions(timestep=mw.timestep, n_iterations=4), n_envs=3, data=data, buffer_size=4)
+    simw.reset()
+    simw.physics.step(30)
+    sw = data.sensors
+    rows = _lib.CRows(); rows.links = sw.links.array[2].data_ptr(); rows.joints = sw.joints.array[2].data_ptr()
+    c = simw.physics._cdata(); u = simw.task.units.as_c()
+    _lib.check(simw.physics._lib.fmj_physics2data(simw.physics._ctx, ctypes.byref(c), ctypes.byref(rows), ctypes.byref(u), 0,
+                                                  ctypes.c_void_p(torch.cuda.current_stream(simw.physics.device).cuda_stream)))
+    cycontacts2data(physics=simw.physics, iteration=2, data=sw.contacts, geompair2data=simw.task.maps['sensors']['geompair2data'],
+                    meters=simw.task.units.meters, newtons=simw.task.units.newtons)
+    want = [a[2].clone() for a in (sw.links.array, sw.joints.array, sw.contacts.array)]
+    for a in (sw.links.array, sw.joints.array, sw.contacts.array):
+        a.zero_()
+    physics2data(simw.physics, 2, data, simw.task.maps, simw.task.units)
+    for w, a, name in zip(want, (sw.links.array, sw.joints.array, sw.contacts.array), ('links', 'joints', 'contacts')):
+        assert torch.equal(w, a[2]), name
+    assert float(want[2].abs().max()) > 1e-3
