@@ -390,12 +390,18 @@ def main():
             else:
                 sm = [build_sim(per_gpu, n_it, ck, rank*per_gpu, device)[0]]
             bt = BucketedSimulation(sm)
-            for _ in range(4):
+            for _ in range(3):
                 bt.step_fused(ck)
             torch.cuda.synchronize()
+            tw = time.perf_counter()
+            bt.step_fused(ck)
+            torch.cuda.synchronize()
+            est = max(time.perf_counter() - tw, 1e-6)
+            tn = torch.tensor([max(8, int(np.ceil(1.5/est)))], device=device if args.dist_backend == 'nccl' else 'cpu')      # a timed region of >= 1.5 s, the same launches on every rank
+            dist.all_reduce(tn, op=dist.ReduceOp.MAX)
+            nl = int(tn.item())
             dist.barrier()
             t1 = time.perf_counter()
-            nl = 8
             for _ in range(nl):
                 bt.step_fused(ck)
             torch.cuda.synchronize()
