@@ -115,3 +115,59 @@ def test_salamander_with_mesh_feet_and_self_collision_pairs(oracle):
     err = group_relerr(d.qvel.cpu().numpy(), o['qvel'], qvel_groups(m))
     print('mesh feet + self-collision pairs: contact-frame forces', worst, 'qvel per component', err)
     assert worst < 5e-3 and err < 3e-2
+
+
+def test_from_sdf_mesh_collisions_and_self_collisions_end_to_end(oracle, tmp_path):
+    """VERDICT round 4 item 4, through the host API: an SDF animat whose links carry MESH collisions (the reference's usual case,
+    mjcf.py:270-413) plus a box, `morphology.self_collisions` between them (mjcf.py:1012-1033), on a flat arena: Simulation.from_sdf
+    compiles it (hull planes included), the animal folds onto itself under a wave controller and lies on the floor; 300 fused iterations
+    against the oracle stepping the same compiled model."""
+    import torch
+    from farms_mujoco_amd.options import AnimatOptions, ArenaOptions, SimulationOptions, WaterOptions
+    from farms_mujoco_amd.simulation.simulation import Simulation
+    from test_gpu_fused_parity import _SdfWave, _oracle_initial_state
+    oct_ = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1]], float)
+    (tmp_path / 'oct.obj').write_text(''.join(f'v {a} {b} {c}\n' for a, b, c in oct_))
+    link = lambda name, x, geom: f'''<link name="{name}"><pose>{x} 0 0.06 0 0 0</pose>
+        <inertial><mass>0.05</mass><inertia><ixx>2e-5</ixx><iyy>2e-5</iyy><izz>2e-5</izz></inertia></inertial>
+        <collision name="c_{name}"><geometry>{geom}</geometry></collision></link>'''
+    mesh = '<mesh><uri>oct.obj</uri><scale>0.03 0.02 0.04</scale></mesh>'
+    (tmp_path / 'm.sdf').write_text('<sdf version="1.6"><model name="folder">'
+        + link('a', 0.0, mesh) + link('b', 0.07, '<box><size>0.04 0.03 0.03</size></box>') + link('c', 0.14, mesh)
+        + ''.join(f'<joint name="j_{ch}" type="revolute"><parent>{pa}</parent><child>{ch}</child><pose>-0.035 0 0 0 0 0</pose>'
+                  f'<axis><xyz>0 1 0</xyz><limit><lower>-2.6</lower><upper>2.6</upper></limit></axis></joint>' for pa, ch in (('a', 'b'), ('b', 'c')))
+        + '</model></sdf>')
+    ao = AnimatOptions(name='folder', links=[AnimatOptions.link(n, friction=[0.7, 0, 0]) for n in 'abc'],
+                       joints=[AnimatOptions.joint(f'j_{n}', damping=2e-3) for n in 'bc'], motors=[AnimatOptions.motor(f'j_{n}', gains=(0.5, 0.01)) for n in 'bc'],
+                       sdf=str(tmp_path / 'm.sdf'), spawn_pose=(0, 0, 0.0, 0, 0, 0))
+    ao.morphology.self_collisions = [['a', 'c'], ['a', 'b']]
+    n, T = 4, 500
+    opts = SimulationOptions(timestep=1e-3, n_iterations=T)
+    arena = ArenaOptions(water=WaterOptions(height=None, drag=False), ground_height=0.0)
+    from farms_mujoco_amd.simulation.mjcf import setup_model
+    m = setup_model(opts, ao, arena)
+    assert m.npair == 2 and m.nmeshface == 16 and sorted(set(np.asarray(m.geom_type)[np.asarray(m.pair_geom2)])) == [6, 7]
+    from farms_mujoco_amd.data import AnimatData
+    ctl = _SdfWave(m, np.zeros(n))
+    ctl.amplitude = ctl.amplitude*8.0                       # +-2 rad: the chain folds until link c meets link a (after ~290 steps)
+    pairs = [('a', 'c'), ('a', 'b'), ('c', '')]
+    data = AnimatData(1e-3, T, n, m.body_names[1:], m.hinge_joint_names(), contacts=pairs)
+    sim = Simulation.from_sdf(opts, ao, arena, n_envs=n, buffer_size=T, controller=ctl, data=data)
+    sim.reset()
+    m = sim.physics.model
+    st = _oracle_initial_state(oracle, sim, m)
+    sim.run(fused=True)
+    torch.cuda.synchronize()
+    g2d = sim.task.maps['sensors']['geompair2data']
+    ref = oracle.run_fused(m, st, T, buffer_size=T, controller=1, geompair2data=g2d, n_contact_rows=len(pairs),
+                           wave=dict(amplitude=ctl.amplitude.cpu().numpy(), phase_lag=ctl.phase_lag.cpu().numpy(),
+                                     env_phase=ctl.env_phase.cpu().numpy(), frequency=ctl.frequency))
+    d = sim.physics.data
+    assert int(d.status.abs().sum()) == 0
+    rows = data.sensors.contacts.array.cpu().numpy(); want = ref['contacts']
+    self_force = np.abs(want[:, :, 0, 6:9]).max()           # total force of the (a, c) sensor: mesh against mesh
+    assert self_force > 1e-3, 'link c never met link a'
+    e = np.abs(d.qpos.cpu().numpy() - ref['qpos']).max(1)
+    ec = np.abs(rows[..., :9] - want[..., :9]).max()/np.abs(want[..., :9]).max()
+    print('from_sdf with mesh collisions + self_collisions: qpos abs err per env', e, 'contact rows', ec, 'peak self-contact force', self_force)
+    assert e.max() < 5e-4 and ec < 2e-2
