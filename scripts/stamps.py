@@ -3,7 +3,7 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from farms_mujoco_amd import _lib
-_lib.SO_PATH = os.path.join(_lib.CSRC, 'libfmj_hip_stamps.so')
+_lib.SO_PATH = os.path.join(_lib.CSRC, os.environ.get('FMJ_STAMPS_SO', 'libfmj_hip_stamps.so'))
 import torch, bench
 names = ['emit+drag', 'joints row', 'K', 'C', 'V', 'F+carry', 'S', 'Q', 'M', 'L', 'X', 'Euler', 'facM', 'collide', 'Jrows', 'rowprm', 'Y',
          'A|nwt-start', 'warm|nwt-H', 'PGS|nwt-update', 'qfrc_c', 'nwt-factor', 'nwt-solve', 'nwt-linesearch']
