@@ -106,6 +106,7 @@ struct DevModel {
   // ---- two-envs-per-wave instantiation (fmj_dual2.inc)
   int dual_ok, dual_t0;                // eligible, translational dofs carried as scalars (3 with a free root)
   int implicitfast;                    // integrator = implicitfast: the velocity gains of unclamped actuators join the damping on the diagonal of H (include/fmj.h)
+  float hdamp;                         // the step by which joint damping enters H = M + diag(armature + hdamp * damping): h (mj_Euler's eulerdamp, implicitfast), 0 with RK4 (qacc = M^-1 ...)
   int cons2_ok;                        // constraints + two envs per wave (fmj_cons2.inc): limits / ground contacts, pyramidal cone, PGS
   float dual_tadd[3];                  // m_total + armature + h*damping of the translational dofs
   float dual_taddm[3];                 // m_total + armature: the same block of M itself (fmj_cons2.inc factors both)
@@ -192,6 +193,8 @@ struct fmj_ctx {
   std::vector<void*> allocs;
   size_t lds_bytes, lds_bytes_dual2, lds_bytes_cons2;
   int* d_resume;              // [n_envs] hand-over of the two-env constraint kernel to the one-env kernel
+  int rk4;                    // integrator = RK4: fmj_step runs four forward launches per step (fmj_rk4_stage_kernel between them)
+  float *rk_q0, *rk_v0, *rk_sv, *rk_sa, *rk_sd;      // [n_envs][nq | nv | nv | nv | nsensordata] X[0], sum B F, the sensordata the later passes may scribble on
   int solver_requested;       // fmj_model.solver as handed in (fmj_create may run the dual solver instead: fmj_solver_info)
   int dual_wps;               // waves per SIMD the dual2 build is registered for: 4, or 3 when the batch cannot fill more (FMJ_WPS overrides)
   fmj_sensor_layout_t layout;
@@ -1565,7 +1568,7 @@ __global__ void __launch_bounds__(64, (CONS || MAXD > 32) ? 2 : 4) fmj_step_kern
       const v3 gi = add3(bf.r, cross(sc, bf.l));
       const float mii = dot3(cd.r, gi) + dot3(cd.l, bf.l);
       hdg_m = isd ? mii + d_prm.x : 1.f;
-      hdg_h = isd ? mii + (d_prm.x + M.h * (d_prm.y + dvel)) : 1.f;
+      hdg_h = isd ? mii + (d_prm.x + M.hdamp * (d_prm.y + dvel)) : 1.f;
       const int maxdep = M.maxdep1;
 #pragma unroll
       for (int g = 0; g < MAXD / 4; g++) {
@@ -2053,6 +2056,75 @@ __device__ __forceinline__ void drag_rows_of_env(const DevModel& M, const StepAr
 }
 __global__ void __launch_bounds__(64) fmj_drag_kernel(const DevModel M, const StepArgs A) { drag_rows_of_env(M, A, blockIdx.x); }
 
+// mj_RungeKutta(m, d, 4) (oracle rk4): the state update between the four forward passes of a step.  The passes themselves are launches of the
+// step kernel with integrate = 0 (fmj_step's RK4 branch); this kernel advances qpos / qvel to the next stage's state X[s + 1] = X[0] (+) h A[s] F[s]
+// (F[s] = the velocity the pass ran at and the acceleration it returned) and accumulates sum B[s] F[s]; after the fourth pass it commits
+// X[0] (+) h sum B F, saves that pass's qacc as the warm start and advances time (mj_advance).  Lane = body (its joint), one wave per env.
+struct RkArgs { float* q0; float* v0; float* sv; float* sa; int stage; };
+__global__ void __launch_bounds__(64) fmj_rk4_stage_kernel(const DevModel M, const StepArgs A, const RkArgs R) {
+  const int env = blockIdx.x, lane = threadIdx.x;
+  if (env >= A.n_envs) return;
+  if ((A.status[env] & FMJ_WARN_FREEZE) != 0) return;            // a frozen env keeps its last finite state (include/fmj.h)
+  const int nq = M.nq, nv = M.nv;
+  float* q = A.qpos + (size_t)env * nq; float* v = A.qvel + (size_t)env * nv;
+  const float* a = A.qacc + (size_t)env * nv;
+  float* q0 = R.q0 + (size_t)env * nq; float* v0 = R.v0 + (size_t)env * nv;
+  float* sv = R.sv + (size_t)env * nv; float* sa = R.sa + (size_t)env * nv;
+  const int s = R.stage;
+  const float rb = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+  const float ra = s < 2 ? 0.5f : 1.0f;
+  const bool isb = lane >= 1 && lane < M.nbody;
+  const int4 ci = BTABI(lane < M.nbody ? lane : 0, 7);           // parent, jtype, qadr, dadr
+  const int jtype = isb ? ci.y : -1, qadr = ci.z, dadr = ci.w;
+  const int nd = jtype == FMJ_JNT_FREE ? 6 : ((jtype == FMJ_JNT_HINGE || jtype == FMJ_JNT_SLIDE) ? 1 : 0);
+  const int nqj = jtype == FMJ_JNT_FREE ? 7 : nd;
+  float vs[6], as[6], svn[6], san[6], q0j[7];
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    const bool on = k < nd;
+    vs[k] = on ? v[dadr + k] : 0.f; as[k] = on ? a[dadr + k] : 0.f;
+    svn[k] = fmaf(rb, vs[k], (on && s > 0) ? sv[dadr + k] : 0.f); san[k] = fmaf(rb, as[k], (on && s > 0) ? sa[dadr + k] : 0.f);
+  }
+#pragma unroll
+  for (int k = 0; k < 7; k++) q0j[k] = k < nqj ? (s == 0 ? q[qadr + k] : q0[qadr + k]) : 0.f;
+  float v0j[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) v0j[k] = k < nd ? (s == 0 ? vs[k] : v0[dadr + k]) : 0.f;
+  // the step the positions take from X[0], and the velocity they take it with: the stage's own (s < 3), the weighted sum (s == 3)
+  const float hs = s < 3 ? M.h * ra : M.h;
+  float vv[6], vn[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { vv[k] = s < 3 ? vs[k] : svn[k]; vn[k] = fmaf(hs, s < 3 ? as[k] : san[k], v0j[k]); }
+  if (nd > 0) {
+    int warn = 0;                                                  // mj_checkAcc / mj_checkVel on what this stage commits
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < nd) { if (!(fabsf(as[k]) <= 1e10f)) warn |= FMJ_WARN_BADQACC; if (!(fabsf(vn[k]) <= 1e10f)) warn |= FMJ_WARN_BADQVEL; }
+    if (warn) { atomicOr(&A.status[env], warn); return; }
+    if (s == 0) {
+#pragma unroll
+      for (int k = 0; k < 7; k++) if (k < nqj) q0[qadr + k] = q0j[k];
+#pragma unroll
+      for (int k = 0; k < 6; k++) if (k < nd) v0[dadr + k] = v0j[k];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) if (k < nd) { sv[dadr + k] = svn[k]; sa[dadr + k] = san[k]; v[dadr + k] = vn[k]; }
+    if (jtype == FMJ_JNT_FREE) {
+      q[qadr] = fmaf(hs, vv[0], q0j[0]); q[qadr + 1] = fmaf(hs, vv[1], q0j[1]); q[qadr + 2] = fmaf(hs, vv[2], q0j[2]);
+      const v3 w = mk3(vv[3], vv[4], vv[5]);
+      const float n2 = dot3(w, w), rn = rsqrt_nr(n2), n = n2 * rn;
+      q4 qo = {q0j[3], q0j[4], q0j[5], q0j[6]};
+      qo = qnormalize(qo);
+      if (n2 >= 1e-30f) qo = qmul(qo, axisangle_small(scl3(w, rn), hs * n));
+      q[qadr + 3] = qo.w; q[qadr + 4] = qo.x; q[qadr + 5] = qo.y; q[qadr + 6] = qo.z;
+    } else q[qadr] = fmaf(hs, vv[0], q0j[0]);
+    if (s == 3 && A.qacc_warmstart) {
+#pragma unroll
+      for (int k = 0; k < 6; k++) if (k < nd) A.qacc_warmstart[(size_t)env * nv + dadr + k] = as[k];
+    }
+  }
+  if (s == 3 && lane == 0 && A.time) A.time[env] += M.h;
+}
+
 // drag_forces (reference drag.pyx:152-268) of one link in every env: thread = env, rows addressed by an env stride
 __global__ void __launch_bounds__(256) fmj_drag_link_kernel(const int n_envs, const float* links_row, const long long links_stride,
                                                             float* xfrc_row, const long long xfrc_stride, const float4 c0,
@@ -2330,8 +2402,8 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
   // dual block update only (fmj_cons_rows.inc (8c)).  Such a model requested with Newton / CG is solved on the dual problem as well.
   if (cons && m->solver != FMJ_SOLVER_PGS && (m->noslip_iterations > 0 || (m->cone == FMJ_CONE_ELLIPTIC && m->npair > 0))) dual_instead = true;
   if (m->noslip_iterations < 0 || !(m->noslip_tolerance >= 0)) return set_err(FMJ_ERR_ARG, "fmj_create: noslip_iterations / noslip_tolerance must not be negative");
-  if (m->integrator != FMJ_INT_EULER && m->integrator != FMJ_INT_IMPLICITFAST)
-    return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: integrator must be FMJ_INT_EULER or FMJ_INT_IMPLICITFAST (RK4 is four forward passes per step; implicit keeps the Coriolis derivatives, a non-symmetric matrix outside this path's tree-sparse factorisation)");
+  if (m->integrator != FMJ_INT_EULER && m->integrator != FMJ_INT_IMPLICITFAST && m->integrator != FMJ_INT_RK4)
+    return set_err(FMJ_ERR_UNSUPPORTED, "fmj_create: integrator must be FMJ_INT_EULER, FMJ_INT_IMPLICITFAST or FMJ_INT_RK4 (implicit keeps the Coriolis derivatives, a non-symmetric matrix outside this path's tree-sparse factorisation)");
   if (cons && (m->ngeom > nplane || m->npair > 0) && !any_limit && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   if ((m->npair > 0 || (nplane > 0 && m->ngeom > nplane)) && m->max_contacts < 1) return set_err(FMJ_ERR_ARG, "fmj_create: max_contacts must be >= 1 with collision geoms");
   // structure checks: single tree rooted at body 1, DFS pre-order, <= 1 joint per body
@@ -2517,6 +2589,7 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     }
   }
   D.implicitfast = m->integrator == FMJ_INT_IMPLICITFAST;
+  D.hdamp = m->integrator == FMJ_INT_RK4 ? 0.0f : (float)m->timestep;
   D.solver_iterations = dual_instead ? 10 * m->solver_iterations : m->solver_iterations; D.solver_tolerance = (float)m->solver_tolerance;
   D.cone = cons ? m->cone : FMJ_CONE_PYRAMIDAL;
   D.noslip_iterations = cons ? m->noslip_iterations : 0; D.noslip_tolerance = (float)m->noslip_tolerance;
@@ -2631,10 +2704,11 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     const char* envv = getenv("FMJ_DUAL");
     D.dual_t0 = t0;
     const bool halves_ok = nb <= 32 && nv - t0 <= 32 && !(envv && envv[0] == '0');      // bodies / lane dofs of an env fit half a wave
-    D.dual_ok = !cons && halves_ok;
+    const bool rk4 = m->integrator == FMJ_INT_RK4;      // four forward launches of the one-env kernel per step: no two-env kernel, no fused launch
+    D.dual_ok = !cons && halves_ok && !rk4;
     // the two-env constraint kernel covers what BASELINE configs[3] needs: limits + ground contacts of sphere / capsule / box / cylinder
     // geoms on ONE ground geom, pyramidal cone, PGS; everything else (pairs, meshes, Newton / CG, the elliptic cone) keeps the one-env kernel
-    D.cons2_ok = cons && halves_ok && D.rs <= FMJ_MAXD && m->solver == FMJ_SOLVER_PGS && !dual_instead && m->cone == FMJ_CONE_PYRAMIDAL && m->noslip_iterations == 0 && m->npair == 0 &&
+    D.cons2_ok = cons && halves_ok && !rk4 && D.rs <= FMJ_MAXD && m->solver == FMJ_SOLVER_PGS && !dual_instead && m->cone == FMJ_CONE_PYRAMIDAL && m->noslip_iterations == 0 && m->npair == 0 &&
                  !any_mesh && nplane <= 1 && m->ngeom <= 32;
     for (int t = 0; t < 3; t++) D.dual_tadd[t] = t < t0 ? (float)(mtot + m->dof_armature[t] + m->timestep * m->dof_damping[t]) : 1.0f;
     for (int t = 0; t < 3; t++) D.dual_taddm[t] = t < t0 ? (float)(mtot + m->dof_armature[t]) : 1.0f;
@@ -2775,6 +2849,15 @@ int fmj_create(const fmj_model* m, int32_t n_envs, int32_t device, fmj_ctx** out
     if (c->lds_bytes_cons2 > 64 * 1024 || hipMalloc(&pr, (size_t)n_envs * sizeof(int)) != hipSuccess) D.cons2_ok = 0;      // (cannot happen within the size limits above)
     else { c->allocs.push_back(pr); c->d_resume = (int*)pr; (void)hipMemset(pr, 0, (size_t)n_envs * sizeof(int)); }
   }
+  c->rk4 = m->integrator == FMJ_INT_RK4; c->rk_q0 = c->rk_v0 = c->rk_sv = c->rk_sa = c->rk_sd = nullptr;
+  if (c->rk4) {
+    const size_t per_env = (size_t)nq + 3 * (size_t)nv + (size_t)(D.nsensordata > 0 ? D.nsensordata : 1);
+    void* pk = nullptr;
+    if (hipMalloc(&pk, per_env * (size_t)n_envs * sizeof(float)) != hipSuccess) { fmj_destroy(c); return set_err(FMJ_ERR_HIP, "fmj_create: RK4 stage buffers"); }
+    c->allocs.push_back(pk);
+    c->rk_q0 = (float*)pk; c->rk_v0 = c->rk_q0 + (size_t)n_envs * nq; c->rk_sv = c->rk_v0 + (size_t)n_envs * nv; c->rk_sa = c->rk_sv + (size_t)n_envs * nv;
+    c->rk_sd = c->rk_sa + (size_t)n_envs * nv;
+  }
   {
     hipDeviceProp_t prop;
     int n_cu = 256;
@@ -2906,6 +2989,27 @@ int fmj_step(fmj_ctx* c, const fmj_data* d, int32_t n_steps, int64_t ctrl_step_s
   if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step: qpos_spring required (model has joint stiffness)");
   A.n_steps = n_steps; A.ctrl_step_stride = ctrl_step_stride; A.integrate = 1;
   HIP_TRY(hipSetDevice(c->device));
+  if (c->rk4) {
+    // mj_step with mjINT_RK4 (oracle rk4): per step four forward launches (mj_forward, then three mj_forwardSkip(skipsensor): their
+    // sensordata goes to a scratch array, so the caller's keeps the first pass's - poses, contacts and contact forces are the last pass's,
+    // as MuJoCo leaves them) with the state update of fmj_rk4_stage_kernel after each.  ctrl and xfrc_applied are held over a step.
+    if (!A.qacc) return set_err(FMJ_ERR_ARG, "fmj_step: the RK4 integrator needs fmj_data.qacc (the stages read the accelerations there)");
+    for (int st = 0; st < n_steps; st++) {
+      StepArgs F = A;
+      F.n_steps = 1; F.integrate = 0; F.ctrl_step_stride = 0;
+      if (A.ctrl && ctrl_step_stride) F.ctrl = A.ctrl + (size_t)st * (size_t)ctrl_step_stride;
+      for (int sg = 0; sg < 4; sg++) {
+        StepArgs G = F;
+        if (sg > 0) G.sensordata = c->rk_sd;
+        int rc2 = launch_step(c, false, G, stream);
+        if (rc2) return rc2;
+        RkArgs R; R.q0 = c->rk_q0; R.v0 = c->rk_v0; R.sv = c->rk_sv; R.sa = c->rk_sa; R.stage = sg;
+        hipLaunchKernelGGL(fmj_rk4_stage_kernel, dim3(c->n_envs), dim3(64), 0, (hipStream_t)stream, c->dm, F, R);
+        HIP_TRY(hipGetLastError());
+      }
+    }
+    return FMJ_OK;
+  }
   return launch_step(c, false, A, stream);
 }
 
@@ -2959,6 +3063,7 @@ int fmj_step_fused(fmj_ctx* c, const fmj_data* d, const fmj_fused_args* a, void*
   if (!c || !a) return set_err(FMJ_ERR_ARG, "fmj_step_fused: NULL argument");
   StepArgs A; int rc = fill_data(c, d, &A, true); if (rc) return rc;
   if (a->n_steps < 0 || a->buffer_size < 1) return set_err(FMJ_ERR_ARG, "fmj_step_fused: bad n_steps/buffer_size");
+  if (c->rk4) return set_err(FMJ_ERR_UNSUPPORTED, "fmj_step_fused: the RK4 integrator steps through fmj_step (four forward launches per step); write the rows with fmj_before_step");
   if (c->dm.any_stiffness && !d->qpos_spring) return set_err(FMJ_ERR_ARG, "fmj_step_fused: qpos_spring required");
   if (a->do_readout && (!a->rows_base.links || !a->rows_base.joints)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: readout needs links and joints rows");
   if (a->do_drag && (!a->rows_base.xfrc || c->dm.ns == 0)) return set_err(FMJ_ERR_ARG, "fmj_step_fused: drag needs xfrc rows and fmj_set_swimming");

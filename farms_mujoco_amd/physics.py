@@ -66,6 +66,7 @@ class BatchedPhysics:
             xfrc_applied=z(n, m.nbody, 6), xpos=z(n, m.nbody, 3), xquat=z(n, m.nbody, 4), xipos=z(n, m.nbody, 3),
             sensordata=z(n, m.nsensordata), qacc=z(n, m.nv), time=z(n), status=z(n, dtype=torch.int32))
         self.has_constraints = bool(np.any(m.jnt_limited)) or m.ngeom > 0
+        self.rk4 = int(getattr(m, 'integrator', 0)) == 1      # FMJ_INT_RK4: fmj_step runs four forward launches per step, fmj_step_fused refuses
         self.max_contacts = max(int(m.max_contacts), 1)
         self.data.qacc_warmstart = z(n, m.nv)
         self.data.contact = z(n, self.max_contacts, 16)

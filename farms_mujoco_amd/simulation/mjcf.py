@@ -48,8 +48,9 @@ def check_supported_options(simulation_options, compile_only=False):
     """What of ``simulation_options.integrator / cone / solver / noslip_iterations`` (forwarded to MuJoCo's option block by the reference,
     mjcf.py:1342-1403) the HIP step implements; anything else would silently run different physics, so it is refused HERE with the
     reason (and again by ``fmj_create``):
-      integrator  Euler (with MuJoCo's implicit joint damping) and implicitfast.  RK4 is four forward passes per step; ``implicit``
-                  keeps the Coriolis derivatives, a non-symmetric matrix outside the tree-sparse L'DL of this path.
+      integrator  Euler (with MuJoCo's implicit joint damping), implicitfast, and RK4 (round 5: four forward launches per step through
+                  fmj_step - the per-iteration path, no fused launch).  ``implicit`` keeps the Coriolis derivatives, a non-symmetric
+                  matrix outside the tree-sparse L'DL of this path.
       solver/cone PGS, CG or Newton with the pyramidal or the elliptic cone (round 5: MuJoCo's elliptic PGS - ray update + friction QCQP per
                   contact - on the device too, also on models with explicit pairs).
       noslip      MuJoCo's post-pass on the friction rows without regularisation: oracle and device (round 5); requested with Newton / CG
@@ -57,8 +58,8 @@ def check_supported_options(simulation_options, compile_only=False):
     if simulation_options is None:
         return
     for name, supported, why in (
-            ('integrator', ('euler', 'implicitfast'), 'MuJoCo also has RK4 (four forward passes per step) and implicit (Coriolis derivatives: a non-symmetric '
-                                                     'matrix outside this path\'s tree-sparse factorisation)'),
+            ('integrator', ('euler', 'implicitfast', 'rk4'), 'MuJoCo also has implicit (Coriolis derivatives: a non-symmetric '
+                                                            'matrix outside this path\'s tree-sparse factorisation)'),
             ('cone', ('pyramidal', 'elliptic'), ''), ('solver', ('pgs', 'cg', 'newton'), '')):
         value = getattr(simulation_options, name, None)
         if value is not None and str(value).lower() not in supported:

@@ -51,6 +51,8 @@ class Simulation:
         self.task = ExperimentTask(base_link=base_link, n_iterations=self.options.n_iterations,
                                    timestep=self.options.timestep, units=self.options.units,
                                    substeps=self.options.num_sub_steps, **kwargs)
+        # RK4 (four forward launches per step, fmj_step): no fused launch, the controller is evaluated on the host path (task.step_control)
+        self.task.host_step_only = self.physics.rk4
         self._needs_reset = True
 
     @property

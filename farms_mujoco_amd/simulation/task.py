@@ -183,7 +183,7 @@ class ExperimentTask:
         a device controller (``fusable``) in a run without sub-steps whose host callbacks do not write ``physics.data.ctrl``
         (``TaskCallback.writes_ctrl``).  Same semantics as the fused path: actuators the controller does not drive get ctrl 0."""
         c = self._controller
-        return (c is not None and getattr(c, 'fusable', False) and self.substeps == 1
+        return (c is not None and getattr(c, 'fusable', False) and self.substeps == 1 and not getattr(self, 'host_step_only', False)
                 and not any(getattr(cb, 'writes_ctrl', False) for cb in self._callbacks))
 
     def before_step(self, action, physics, rows_written=False):
@@ -290,4 +290,4 @@ class ExperimentTask:
         sub-steps, links-only rows and the iteration counter as before_step / after_step do (include/fmj.h)."""
         cbs_ok = all(getattr(cb, 'fusable', False) for cb in self._callbacks)
         ctl_ok = self._controller is None or getattr(self._controller, 'fusable', False)
-        return cbs_ok and ctl_ok
+        return cbs_ok and ctl_ok and not getattr(self, 'host_step_only', False)

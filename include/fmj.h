@@ -47,7 +47,11 @@ enum { FMJ_CONE_PYRAMIDAL = 0, FMJ_CONE_ELLIPTIC = 1 };
  * joint-transmission actuators, joint spring-dampers, no fluid or tendon forces - the velocity derivative of the smooth forces that
  * implicitfast keeps (passive + actuation, Coriolis terms dropped) is DIAGONAL: joint damping plus the velocity gain (-biasprm[2]) of
  * every actuator whose force is not clamped by its forcerange, so implicitfast is the Euler step with that sum in place of the damping.
- * RK4 (four forward passes per step) and implicit (the full, non-symmetric derivative incl. Coriolis terms, LU-factored) are refused. */
+ * RK4 (round 5): mj_RungeKutta with the classical tableau - per step four forward passes (launches of the step kernel with the integration
+ * off) and a small kernel that advances the state between them; qacc is M^-1 (...) without the implicit damping, sensordata keeps the first
+ * pass's values, poses / contacts / contact forces the last pass's (what mj_step leaves in mjData).  RK4 steps through fmj_step only
+ * (fmj_data.qacc required); fmj_step_fused refuses it.  implicit (the full, non-symmetric derivative incl. Coriolis terms, LU-factored)
+ * is refused. */
 enum { FMJ_INT_EULER = 0, FMJ_INT_RK4 = 1, FMJ_INT_IMPLICIT = 2, FMJ_INT_IMPLICITFAST = 3 };
 enum { FMJ_GEOM_PLANE = 0, FMJ_GEOM_HFIELD = 1, FMJ_GEOM_SPHERE = 2, FMJ_GEOM_CAPSULE = 3, FMJ_GEOM_CYLINDER = 5, FMJ_GEOM_BOX = 6, FMJ_GEOM_MESH = 7 };   /* mjtGeom values */
 

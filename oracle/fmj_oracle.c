@@ -1507,6 +1507,23 @@ static int forward(const fmj_model* m, ws_t* w, const double* qpos, const double
   return warn;
 }
 
+/* mj_integratePos: qpos advanced by h * vel (quaternion of a free joint: rotated by the angle h |w| about w) */
+static void integrate_pos(const fmj_model* m, double* qpos, const double* vel, double h) {
+  for (int j = 0; j < m->njnt; j++) {
+    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
+    if (m->jnt_type[j] == FMJ_JNT_FREE) {
+      for (int k = 0; k < 3; k++) qpos[qa + k] += h * vel[da + k];
+      double ax[3] = {vel[da + 3], vel[da + 4], vel[da + 5]};
+      double nrm = sqrt(dotn(ax, ax, 3));
+      if (nrm < MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; nrm = 0; } else for (int k = 0; k < 3; k++) ax[k] /= nrm;
+      double qr[4];
+      axis_angle2quat(qr, ax, h * nrm);
+      normalize4(qpos + qa + 3);
+      mul_quat(qpos + qa + 3, qpos + qa + 3, qr);
+    } else qpos[qa] += h * vel[da];
+  }
+}
+
 static void euler(const fmj_model* m, ws_t* w, double* qpos, double* qvel) {
   int nv = m->nv; double h = m->timestep;
   int damped = 0;
@@ -1536,19 +1553,36 @@ static void euler(const fmj_model* m, ws_t* w, double* qpos, double* qvel) {
   }
   free(bd);
   for (int i = 0; i < nv; i++) qvel[i] += h * qacc[i];
-  for (int j = 0; j < m->njnt; j++) {
-    int qa = m->jnt_qposadr[j], da = m->jnt_dofadr[j];
-    if (m->jnt_type[j] == FMJ_JNT_FREE) {
-      for (int k = 0; k < 3; k++) qpos[qa + k] += h * qvel[da + k];
-      double ax[3] = {qvel[da + 3], qvel[da + 4], qvel[da + 5]};
-      double nrm = sqrt(dotn(ax, ax, 3));
-      if (nrm < MINVAL) { ax[0] = 1; ax[1] = ax[2] = 0; nrm = 0; } else for (int k = 0; k < 3; k++) ax[k] /= nrm;
-      double qr[4];
-      axis_angle2quat(qr, ax, h * nrm);
-      normalize4(qpos + qa + 3);
-      mul_quat(qpos + qa + 3, qpos + qa + 3, qr);
-    } else qpos[qa] += h * qvel[da];
+  integrate_pos(m, qpos, qvel, h);
+}
+
+/* mj_RungeKutta(m, d, 4) after the step's mj_forward (recalled from MuJoCo's engine_forward.c, parity unpinned like the rest): the classical
+ * tableau A = [[1/2], [0, 1/2], [0, 0, 1]], B = [1/6, 1/3, 1/3, 1/6].  Stage i forwards the state X[i] = X[0] (+) h A[i-1] F[i-1] with
+ * mj_forwardSkip(mjSTAGE_NONE, skipsensor = 1): positions, velocities, constraints and qacc are recomputed, sensordata keeps the values of the
+ * step's first forward pass; positions are advanced with mj_integratePos from X[0] by the stage's VELOCITY, velocities by its acceleration.
+ * No implicit damping: qacc is M^-1 (...) (the Euler-only eulerdamp does not apply).  The warm start of all four passes is the previous step's
+ * (mj_advance saves qacc - the fourth pass's - at the end).  ctrl and xfrc_applied are held over the step. */
+static int rk4(const fmj_model* m, ws_t* w, double* qpos, double* qvel, const double* ctrl, const double* qpos_spring, const double* xfrc) {
+  static const double RA[3] = {0.5, 0.5, 1.0}, RB[4] = {1.0 / 6, 1.0 / 3, 1.0 / 3, 1.0 / 6};
+  int nq = m->nq, nv = m->nv, warn = 0;
+  double* q0 = (double*)malloc(sizeof(double) * (size_t)(nq + 3 * nv + 1));
+  double* v0 = q0 + nq; double* sv = v0 + nv; double* sa = sv + nv;
+  memcpy(q0, qpos, nq * sizeof(double)); memcpy(v0, qvel, nv * sizeof(double));
+  for (int i = 0; i < nv; i++) { sv[i] = RB[0] * qvel[i]; sa[i] = RB[0] * w->qacc[i]; }
+  for (int s = 1; s < 4; s++) {
+    /* X[s]: from X[0] by the derivative of stage s - 1 (its velocity is still in qvel, its acceleration in w->qacc) */
+    memcpy(qpos, q0, nq * sizeof(double));
+    integrate_pos(m, qpos, qvel, m->timestep * RA[s - 1]);
+    for (int i = 0; i < nv; i++) qvel[i] = v0[i] + m->timestep * RA[s - 1] * w->qacc[i];
+    if (g_fp32_storage >= 2) { round_to_f32(qpos, nq); round_to_f32(qvel, nv); }
+    warn |= forward(m, w, qpos, qvel, ctrl, qpos_spring, xfrc, NULL);      /* skipsensor: sensordata stays the first pass's */
+    for (int i = 0; i < nv; i++) { sv[i] += RB[s] * qvel[i]; sa[i] += RB[s] * w->qacc[i]; }
   }
+  memcpy(qpos, q0, nq * sizeof(double));
+  integrate_pos(m, qpos, sv, m->timestep);
+  for (int i = 0; i < nv; i++) qvel[i] = v0[i] + m->timestep * sa[i];
+  free(q0);
+  return warn;
 }
 
 static int bad(const double* x, int n) {
@@ -1574,7 +1608,8 @@ static int step_one(const fmj_model* m, ws_t* w, double* qpos, double* qvel, con
   if (bad(qvel, m->nv)) warn |= FMJ_WARN_BADQVEL;
   warn |= forward(m, w, qpos, qvel, ctrl, qpos_spring, xfrc, sensordata);
   if (bad(w->qacc, m->nv)) warn |= FMJ_WARN_BADQACC;
-  euler(m, w, qpos, qvel);
+  if (m->integrator == FMJ_INT_RK4) { warn |= rk4(m, w, qpos, qvel, ctrl, qpos_spring, xfrc); memcpy(w->tmpv, w->qacc, m->nv * sizeof(double)); }   /* the reported qacc: the last pass's */
+  else euler(m, w, qpos, qvel);
   memcpy(w->qacc_warmstart, w->qacc, m->nv * sizeof(double));
   if (g_fp32_storage >= 2) { round_to_f32(qpos, m->nq); round_to_f32(qvel, m->nv); round_to_f32(w->qacc_warmstart, m->nv); }
   return warn;

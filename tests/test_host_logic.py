@@ -195,7 +195,8 @@ def test_unsupported_solver_options_are_refused():
     check_supported_options(None)
     check_supported_options(SimulationOptions(cone='elliptic', solver='PGS'))     # round 5: MuJoCo's elliptic PGS on the device
     check_supported_options(SimulationOptions(noslip_iterations=3))               # round 5: the noslip post-pass
-    for kw, word in ((dict(integrator='RK4'), 'four forward passes'), (dict(integrator='implicit'), 'Coriolis'), (dict(solver='SOR'), 'pgs')):
+    check_supported_options(SimulationOptions(integrator='RK4'))                  # round 5: mj_RungeKutta through fmj_step
+    for kw, word in ((dict(integrator='implicit'), 'Coriolis'), (dict(solver='SOR'), 'pgs')):
         with pytest.raises(NotImplementedError, match=word):      # a refusal says why
             check_supported_options(SimulationOptions(**kw))
 

@@ -163,10 +163,10 @@ def test_model_size_limits_are_refused_with_a_message_that_names_them():
     rc, msg = create(m)
     assert rc in (0, 4), (rc, msg)
     m = salamander33()
-    for integ, ok in ((0, True), (3, True), (1, False), (2, False), (9, False)):     # Euler, implicitfast | RK4, implicit, junk
+    for integ, ok in ((0, True), (3, True), (1, True), (2, False), (9, False)):     # Euler, implicitfast, RK4 (round 5) | implicit, junk
         m.integrator = integ
         rc, msg = create(m)
-        assert (rc in (0, 4)) if ok else (rc == 2 and 'FMJ_INT_IMPLICITFAST' in msg and 'RK4' in msg), (integ, rc, msg)
+        assert (rc in (0, 4)) if ok else (rc == 2 and 'FMJ_INT_IMPLICITFAST' in msg and 'Coriolis' in msg), (integ, rc, msg)
     m = salamander33(contacts=True, limits=True)
     m.noslip_iterations = 3                                  # round 5: the noslip post-pass is implemented
     rc, msg = create(m)
