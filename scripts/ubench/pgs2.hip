@@ -7,6 +7,8 @@
 //   5  TWO rows per lane (rows l and l + 16 of the lane's env in lanes l and l + 16 alike): the update comes as a DPP row_newbcast
 //      operand of the two fmacs - no readlane, no scalar: v_max, v_cndmask, two v_fmac_dpp
 //   6  as 5, v_max and the capture under a two-lane exec mask written by the scalar unit (cand keeps each lane's own update)
+//   10 three vector instructions per turn: v_max_f32_dpp under the bank mask latches the update itself (register e & 3 of the set), the two fmacs read it
+//      through DPP; four turns are one asm statement.  The force comes from the latched update; no residual is captured (res + nf are compared)
 //   8, 9  calibration: a chain of dependent v_fmac / eight independent chains (ticks per VALU instruction)
 // Build: hipcc --offload-arch=gfx950 -O3 scripts/ubench/pgs2.hip -o scripts/ubench/pgs2
 #include <hip/hip_runtime.h>
@@ -23,7 +25,7 @@ template <int V, int NR> __global__ void k(float* out, unsigned long long* cyc, 
   float res = 0.01f * (lane & 31) - 0.3f + 0.001f * upper, nf = -0.1f * (lane % 3);
   float acc = 0.f, res1 = 0.f, nf1 = 0.f;
   const unsigned long long pairbase = 0x0000000100000001ull, lomask = 0x00000000ffffffffull, pairbase16 = 0x0001000100010001ull;
-  if (V >= 5 && V <= 7) {      // rows l and l + 16 into lanes l and l + 16 alike: v_permlane16_swap (gfx950) trades the odd rows of 16 lanes of its first
+  if ((V >= 5 && V <= 7) || V == 10) {      // rows l and l + 16 into lanes l and l + 16 alike: v_permlane16_swap (gfx950) trades the odd rows of 16 lanes of its first
                                // operand for the even ones of its second
 #pragma unroll
     for (int i = 0; i < 32; i++) { float y = areg[i]; asm volatile("v_permlane16_swap_b32_e32 %0, %1" : "+v"(areg[i]), "+v"(y)); areg[32 + i] = y; }
@@ -55,7 +57,7 @@ template <int V, int NR> __global__ void k(float* out, unsigned long long* cyc, 
     float capr = 0.f;
 #pragma unroll
     for (int e = 0; e < NR; e++) {
-      if (V >= 5 && V <= 7) break;
+      if ((V >= 5 && V <= 7) || V == 10) break;
       if (V == 4) {      // hand-scheduled turn: 7 issue slots, the waits (VALU write -> v_readlane: 1; v_readlane's SGPR -> VALU read: 2) filled by its own instructions
         float cand; unsigned long long bit_; float sa, sb;
         asm volatile("v_max_f32_e32 %[cand], %[nf], %[res]\n\t"
@@ -90,6 +92,44 @@ template <int V, int NR> __global__ void k(float* out, unsigned long long* cyc, 
         asm volatile("v_cndmask_b32_e64 %0, %0, %1, %2" : "+v"(capr) : "v"(res), "s"(bit_));
         res = fmaf(areg[e], upper ? ub : ua, res);
       }
+    }
+    if (V == 10) {
+      static_assert(V != 10 || NR == 24, "variant 10 is written for 24 rows");
+      float dq[8];
+#pragma unroll
+      for (int i = 0; i < 8; i++) dq[i] = 0.f;
+      // S = the set the bank's turns read, O = the other; l_i = the previous turn's column of O, a_i = the turn's column of S
+#define T10(i, lp_, dp_) \
+        "v_max_f32_dpp %[d" #i "], %[nf], %[S] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:%[bm]\n\t" \
+        "v_fmac_f32_dpp %[O], %[" dp_ "], %[l" #i "] row_newbcast:%[" lp_ "] row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 0\n\t" \
+        "v_fmac_f32_dpp %[S], %[d" #i "], %[a" #i "] row_newbcast:%[e" #i "] row_mask:0xf bank_mask:0xf\n\t"
+#define T10X(i, lp_, dp_) \
+        "v_max_f32_dpp %[d" #i "], %[nf], %[S] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:%[bm]\n\t" \
+        "v_fmac_f32_dpp %[O], %[" dp_ "], %[l" #i "] row_newbcast:%[" lp_ "] row_mask:0xf bank_mask:0xf\n\t" \
+        "s_nop 1\n\t" \
+        "v_fmac_f32_dpp %[O], %[d" #i "], %[a" #i "] row_newbcast:%[e" #i "] row_mask:0xf bank_mask:0xf\n\t"
+#define T10OPS(E0_, s_, XL_, dprev_) \
+        : [S] "+v"(s_ ? res1 : res), [O] "+v"(s_ ? res : res1), [d0] "+v"(dq[4 * s_]), [d1] "+v"(dq[4 * s_ + 1]), [d2] "+v"(dq[4 * s_ + 2]), [d3] "+v"(dq[4 * s_ + 3]) \
+        : [nf] "v"(s_ ? nf1 : nf), [dp] "v"(dprev_), [bm] "n"(1 << (((E0_) & 15) >> 2)), \
+          [a0] "v"(areg[32 * s_ + (E0_)]), [a1] "v"(areg[32 * s_ + (E0_) + 1]), [a2] "v"(areg[32 * s_ + (E0_) + 2]), [a3] "v"(areg[32 * (XL_ ? 1 - s_ : s_) + (E0_) + 3]), \
+          [l0] "v"(areg[32 * (1 - s_) + ((E0_) > 0 ? (E0_) - 1 : 0)]), [l1] "v"(areg[32 * (1 - s_) + (E0_)]), [l2] "v"(areg[32 * (1 - s_) + (E0_) + 1]), [l3] "v"(areg[32 * (1 - s_) + (E0_) + 2]), \
+          [em] "n"(((E0_) + 15) & 15), [e0] "n"((E0_) & 15), [e1] "n"(((E0_) + 1) & 15), [e2] "n"(((E0_) + 2) & 15), [e3] "n"(((E0_) + 3) & 15)
+      asm volatile("s_nop 1\n\tv_max_f32_dpp %[d0], %[nf], %[S] quad_perm:[0,1,2,3] row_mask:0xf bank_mask:%[bm]\n\ts_nop 1\n\tv_fmac_f32_dpp %[S], %[d0], %[a0] row_newbcast:%[e0] row_mask:0xf bank_mask:0xf\n\t"
+                   T10(1, "e0", "d0") T10(2, "e1", "d1") T10(3, "e2", "d2") T10OPS(0, 0, 0, dq[0]));
+      asm volatile(T10(0, "em", "dp") T10(1, "e0", "d0") T10(2, "e1", "d1") T10(3, "e2", "d2") T10OPS(4, 0, 0, dq[3]));
+      asm volatile(T10(0, "em", "dp") T10(1, "e0", "d0") T10(2, "e1", "d1") T10(3, "e2", "d2") T10OPS(8, 0, 0, dq[3]));
+      asm volatile(T10(0, "em", "dp") T10(1, "e0", "d0") T10(2, "e1", "d1") T10X(3, "e2", "d2") T10OPS(12, 0, 1, dq[3]));
+      asm volatile(T10(0, "em", "dp") T10(1, "e0", "d0") T10(2, "e1", "d1") T10(3, "e2", "d2") T10OPS(16, 1, 0, dq[3]));
+      asm volatile(T10(0, "em", "dp") T10(1, "e0", "d0") T10(2, "e1", "d1") T10X(3, "e2", "d2") T10OPS(20, 1, 1, dq[7]));
+      asm volatile("s_nop 1\n\tv_fmac_f32_dpp %[rp], %[cp], %[ap] row_newbcast:7 row_mask:0xf bank_mask:0xf" : [rp] "+v"(res1) : [cp] "v"(dq[7]), [ap] "v"(areg[32 + 23]));
+      const int q = lane & 3;
+      float d0 = q == 0 ? dq[0] : q == 1 ? dq[1] : q == 2 ? dq[2] : dq[3];
+      float d1 = q == 0 ? dq[4] : q == 1 ? dq[5] : q == 2 ? dq[6] : dq[7];
+      if ((lane & 15) >= NR) d0 = 0.f;
+      if ((lane & 15) + 16 >= NR) d1 = 0.f;
+      nf -= d0; nf1 -= d1;
+      continue;
     }
     if (V >= 5 && V <= 7) {
       // lanes l and l + 16 of a half both hold rows l (res, nf, areg[0..31]) and l + 16 (res1, nf1, areg[32..63]) - set up below
@@ -182,7 +222,7 @@ template <int V, int NR> __global__ void k(float* out, unsigned long long* cyc, 
     nf -= capc; acc += capc * capr;
   }
   unsigned long long t1 = __builtin_amdgcn_s_memtime();
-  if ((V >= 5 && V <= 7) && (lane & 16)) { res = res1; nf = nf1; }
+  if (((V >= 5 && V <= 7) || V == 10) && (lane & 16)) { res = res1; nf = nf1; }
   out[threadIdx.x + blockIdx.x * blockDim.x] = res + nf + acc;
   if (blockIdx.x == 0 && threadIdx.x < 64) { out[4096 + 3 * threadIdx.x] = res; out[4096 + 3 * threadIdx.x + 1] = nf; out[4096 + 3 * threadIdx.x + 2] = acc; }
   if (threadIdx.x == 0 && blockIdx.x == 0) cyc[0] = t1 - t0;
@@ -191,7 +231,7 @@ int main() {
   float* out; unsigned long long* cyc;
   (void)hipMalloc(&out, 4 * 65536); (void)hipMalloc(&cyc, 16);
   const int sweeps = 2000;
-  float h[10][64]; static float h3[10][192]; static float hc[10][64];
+  float h[11][64]; static float h3[11][192]; static float hc[11][64];
 #define RUN(V, NR, THREADS, label) { hipLaunchKernelGGL((k<V, NR>), dim3(1), dim3(THREADS), 0, 0, out, cyc, sweeps); hipLaunchKernelGGL((k<V, NR>), dim3(1), dim3(THREADS), 0, 0, out, cyc, sweeps); \
   unsigned long long c; (void)hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost); \
   hipLaunchKernelGGL((k<V, NR>), dim3(1), dim3(THREADS), 0, 0, out, cyc + 1, 3);      /* the results compared: three sweeps, far from the fixed point every variant reaches */ \
@@ -205,11 +245,13 @@ int main() {
   RUN(5, 24, 64, "5 two rows per lane, DPP row_newbcast operands (4 VALU)") RUN(5, 24, 512, "5 two rows per lane, DPP row_newbcast operands (4 VALU)")
   RUN(6, 24, 64, "6 as 5, capture = DPP move under a bank mask, s_nop (no scalar)") RUN(6, 24, 512, "6 as 5, capture = DPP move under a bank mask, s_nop (no scalar)")
   RUN(7, 24, 64, "7 as 6, the second row set's fmac one turn late (4 slots)") RUN(7, 24, 512, "7 as 6, the second row set's fmac one turn late (4 slots)")
+  RUN(10, 24, 64, "10 three vector instructions: the bank-masked v_max_dpp latches the update") RUN(10, 24, 512, "10 three vector instructions: the bank-masked v_max_dpp latches the update")
   RUN(8, 64, 64, "8 calibration: dependent v_fmac chain (ticks per instruction)") RUN(8, 64, 512, "8 calibration: dependent v_fmac chain")
   RUN(9, 64, 64, "9 calibration: eight independent v_fmac chains") RUN(9, 64, 512, "9 calibration: eight independent v_fmac chains")
   int bad = 0;
   for (int v = 1; v < 8; v++) for (int i = 0; i < 64; i++) { bad += h[v][i] != h[0][i]; if (h[v][i] != h[0][i] && v == 7) printf("variant %d lane %d: %.9g against %.9g  res %.9g/%.9g nf %.9g/%.9g acc %.9g/%.9g\n", v, i, h[v][i], h[0][i], h3[v][3*i], h3[5][3*i], h3[v][3*i+1], h3[5][3*i+1], h3[v][3*i+2], h3[5][3*i+2]); }
   for (int i = 0; i < 64; i++) if (hc[7][i] != hc[5][i]) printf("capture of sweep 0, lane %d: %.9g (7) %.9g (6) against %.9g (5)\n", i, hc[7][i], hc[6][i], hc[5][i]);
+  { int b10 = 0; for (int i = 0; i < 64; i++) b10 += (h3[10][3 * i] != h3[0][3 * i]) || (h3[10][3 * i + 1] != h3[0][3 * i + 1]); printf("variant 10: lanes whose residual or force differ from variant 0: %d of 64\n", b10); }
   printf("results differing from variant 0: %d of 448\n", bad);
   return 0;
 }

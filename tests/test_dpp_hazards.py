@@ -1,5 +1,5 @@
-"""The PGS turn of the two-env constraint kernel is inline asm (csrc/fmj_cons2_rows.inc PGS_T4): inside it the compiler pads no hazards, and
-the rule that matters there - a DPP instruction must not read a VGPR a VALU instruction wrote fewer than two wait states earlier - is kept by
+"""The PGS turn of the two-env constraint kernel is inline asm (csrc/fmj_cons2_rows.inc PGS_QUAD_D / PGS_TURN_S): inside it the compiler pads no hazards, and
+the rule that matters there - the DPP operand of a DPP instruction must not be a VGPR a VALU instruction wrote fewer than two wait states earlier - is kept by
 the order of the turn's own instructions.  This test compiles the kernel to assembly (hipcc cross-compiles without a GPU) and checks the rule
 on what the compiler actually emitted, its own DPP code included (scripts/dpp_hazards.py)."""
 import os
